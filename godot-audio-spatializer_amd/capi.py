@@ -1,0 +1,286 @@
+"""ctypes binding of libgas_amd.so (include/gas_amd.h).
+
+Fails loudly when the HIP library is missing or cannot be loaded: there is no CPU path.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import build as _build
+
+MAX_CHANNELS = 4
+LOOKAHEAD = 64
+HRTF_TAPS = 256
+ER_TAPS = 8
+
+KIND_3D_MIX = 0
+KIND_3D_PROCESS = 1
+KIND_EFFECT = 2
+FX_HIGHSHELF = 1
+FX_EARLY_REFLECTIONS = 2
+FX_HRTF = 3
+MEM_HOST = 0
+MEM_DEVICE = 1
+
+STATUS = {
+    0: "GAS_OK",
+    -1: "GAS_ERR_INVALID_ARGUMENT",
+    -2: "GAS_ERR_OUT_OF_SLOTS",
+    -3: "GAS_ERR_BAD_SLOT",
+    -4: "GAS_ERR_FRAME_COUNT",
+    -5: "GAS_ERR_NO_HRTF",
+    -6: "GAS_ERR_UNSUPPORTED_CHAIN",
+    -7: "GAS_ERR_DEVICE",
+    -8: "GAS_ERR_NO_DEVICE",
+    -9: "GAS_ERR_OUT_OF_MEMORY",
+    -10: "GAS_ERR_KIND_MISMATCH",
+    -11: "GAS_ERR_BAD_CHANNEL",
+    -12: "GAS_ERR_NO_PARAMS",
+}
+
+# gas_params, 128 bytes (include/gas_amd.h)
+PARAMS_DTYPE = np.dtype(
+    [
+        ("mix_volumes", np.float32, (MAX_CHANNELS, 2)),
+        ("pitch_scale", np.float32),
+        ("linear_attenuation", np.float32),
+        ("attenuation_filter_cutoff_hz", np.float32),
+        ("update_parameters", np.uint32),
+        ("hrtf_gain", np.float32),
+        ("hrtf_dir", np.uint32),
+        ("fx_shelf_gain", np.float32),
+        ("fx_shelf_cutoff_hz", np.float32),
+        ("er_gain", np.float32, (ER_TAPS,)),
+        ("er_delay", np.uint32, (ER_TAPS,)),
+    ]
+)
+assert PARAMS_DTYPE.itemsize == 128
+
+
+class Config(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_uint32),
+        ("device", C.c_int32),
+        ("max_sources", C.c_uint32),
+        ("frames", C.c_uint32),
+        ("channel_count", C.c_uint32),
+        ("mix_rate", C.c_float),
+        ("er_ring_frames", C.c_uint32),
+        ("flags", C.c_uint32),
+    ]
+
+
+class Profile(C.Structure):
+    _fields_ = [
+        ("launches", C.c_uint64),
+        ("kernel_ms", C.c_double),
+        ("bytes_per_launch", C.c_uint64),
+        ("kernel_name", C.c_char * 64),
+    ]
+
+
+# every symbol include/gas_amd.h declares
+EXPORTS = [
+    "gas_abi_version",
+    "gas_ctx_create",
+    "gas_ctx_destroy",
+    "gas_ctx_set_stream",
+    "gas_ctx_synchronize",
+    "gas_strerror",
+    "gas_last_device_error",
+    "gas_source_alloc",
+    "gas_source_free",
+    "gas_source_reset",
+    "gas_params_publish",
+    "gas_params_publish_batch",
+    "gas_hrtf_load",
+    "gas_process_block",
+    "gas_process_frames_1",
+    "gas_mix_channel_1",
+    "gas_profile_enable",
+    "gas_profile_read",
+]
+
+
+class GasError(RuntimeError):
+    def __init__(self, status, where, detail=""):
+        self.status = status
+        name = STATUS.get(status, str(status))
+        super().__init__(f"{where}: {name}" + (f" ({detail})" if detail else ""))
+
+
+_lib = None
+
+
+def library_path():
+    return _build.LIB
+
+
+def load_library():
+    """Load libgas_amd.so; raises if it was never built (no fallback of any kind)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = library_path()
+    if not os.path.exists(path):
+        raise RuntimeError(
+            f"{path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). The spatializer has no CPU fallback."
+        )
+    L = C.CDLL(path)
+    vp, u32, i32 = C.c_void_p, C.c_uint32, C.c_int
+    L.gas_abi_version.restype = i32
+    L.gas_ctx_create.argtypes = [C.POINTER(Config), C.POINTER(vp)]
+    L.gas_ctx_destroy.argtypes = [vp]
+    L.gas_ctx_destroy.restype = None
+    L.gas_ctx_set_stream.argtypes = [vp, vp]
+    L.gas_ctx_synchronize.argtypes = [vp]
+    L.gas_strerror.argtypes = [i32]
+    L.gas_strerror.restype = C.c_char_p
+    L.gas_last_device_error.argtypes = [vp]
+    L.gas_last_device_error.restype = C.c_char_p
+    L.gas_source_alloc.argtypes = [vp, i32, C.POINTER(C.c_int32), u32, C.POINTER(u32)]
+    L.gas_source_free.argtypes = [vp, u32]
+    L.gas_source_reset.argtypes = [vp, u32]
+    L.gas_params_publish.argtypes = [vp, u32, vp]
+    L.gas_params_publish_batch.argtypes = [vp, vp, vp, u32, i32]
+    L.gas_hrtf_load.argtypes = [vp, vp, u32, u32]
+    L.gas_process_block.argtypes = [vp, vp, vp, u32, u32, vp, vp, i32]
+    L.gas_process_frames_1.argtypes = [vp, u32, vp, vp, i32]
+    L.gas_mix_channel_1.argtypes = [vp, u32, i32, vp, vp, i32]
+    L.gas_profile_enable.argtypes = [vp, i32]
+    L.gas_profile_read.argtypes = [vp, C.POINTER(Profile), i32]
+    _lib = L
+    return L
+
+
+def _np_ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class SpatializerContext:
+    """Thin object wrapper over one gas_ctx (one GPU)."""
+
+    def __init__(self, max_sources, frames=512, channel_count=1, mix_rate=48000.0, er_ring_frames=0, device=0):
+        self.lib = load_library()
+        self.frames = int(frames)
+        self.channel_count = int(channel_count)
+        self.max_sources = int(max_sources)
+        cfg = Config(C.sizeof(Config), device, max_sources, frames, channel_count, mix_rate, er_ring_frames, 0)
+        h = C.c_void_p()
+        rc = self.lib.gas_ctx_create(C.byref(cfg), C.byref(h))
+        if rc != 0:
+            raise GasError(rc, "gas_ctx_create", self.lib.gas_strerror(rc).decode())
+        self.h = h
+
+    def _check(self, rc, where):
+        if rc != 0:
+            detail = self.lib.gas_strerror(rc).decode()
+            if rc == -7:
+                detail += ": " + self.lib.gas_last_device_error(self.h).decode()
+            raise GasError(rc, where, detail)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.gas_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # ---- slots ----
+    def source_alloc(self, kind, effects=()):
+        fx = (C.c_int32 * max(1, len(effects)))(*effects)
+        slot = C.c_uint32()
+        self._check(self.lib.gas_source_alloc(self.h, kind, fx, len(effects), C.byref(slot)), "gas_source_alloc")
+        return slot.value
+
+    def source_alloc_many(self, n, kind, effects=()):
+        return np.array([self.source_alloc(kind, effects) for _ in range(n)], dtype=np.uint32)
+
+    def source_free(self, slot):
+        self._check(self.lib.gas_source_free(self.h, int(slot)), "gas_source_free")
+
+    def source_reset(self, slot):
+        self._check(self.lib.gas_source_reset(self.h, int(slot)), "gas_source_reset")
+
+    # ---- parameters ----
+    def params_publish(self, slot, params):
+        p = np.ascontiguousarray(params, dtype=PARAMS_DTYPE).reshape(1)
+        self._check(self.lib.gas_params_publish(self.h, int(slot), _np_ptr(p)), "gas_params_publish")
+
+    def params_publish_batch(self, slots, params):
+        s = np.ascontiguousarray(slots, dtype=np.uint32)
+        p = np.ascontiguousarray(params, dtype=PARAMS_DTYPE)
+        assert s.shape == p.shape
+        self._check(self.lib.gas_params_publish_batch(self.h, _np_ptr(s), _np_ptr(p), len(s), MEM_HOST), "gas_params_publish_batch")
+
+    def params_publish_device(self, params_dev_ptr, n, slots=None):
+        sp = None
+        if slots is not None:
+            s = np.ascontiguousarray(slots, dtype=np.uint32)
+            sp = _np_ptr(s)
+        self._check(self.lib.gas_params_publish_batch(self.h, sp, C.c_void_p(params_dev_ptr), n, MEM_DEVICE), "gas_params_publish_batch")
+
+    def hrtf_load(self, hrir):
+        h = np.ascontiguousarray(hrir, dtype=np.float32)
+        assert h.ndim == 3 and h.shape[1] == 2
+        self._check(self.lib.gas_hrtf_load(self.h, _np_ptr(h), h.shape[0], h.shape[2]), "gas_hrtf_load")
+
+    # ---- hot path ----
+    def process_block(self, src, slots):
+        """Host-memory callback: src float32 [n][F][2], slots uint32 [n] -> (mix [C][F][2], peaks [n][2])."""
+        src = np.ascontiguousarray(src, dtype=np.float32)
+        n = src.shape[0] if src.ndim == 3 else 0
+        s = np.ascontiguousarray(slots, dtype=np.uint32)
+        assert len(s) == n
+        out = np.full((self.channel_count, self.frames, 2), np.nan, dtype=np.float32)
+        peaks = np.zeros((max(n, 1), 2), dtype=np.float32)
+        frames = src.shape[1] if src.ndim == 3 else self.frames
+        rc = self.lib.gas_process_block(self.h, _np_ptr(src) if n else None, _np_ptr(s) if n else None, n, frames, _np_ptr(out), _np_ptr(peaks), MEM_HOST)
+        self._check(rc, "gas_process_block")
+        return out, peaks[:n]
+
+    def process_block_raw(self, src_ptr, slots, n, frames, out_ptr, peaks_ptr, mem):
+        """Raw pointers (device or host). slots: numpy uint32 array or None (reuse the previous list)."""
+        sp = None
+        if slots is not None:
+            s = np.ascontiguousarray(slots, dtype=np.uint32)
+            sp = _np_ptr(s)
+        return self.lib.gas_process_block(self.h, C.c_void_p(src_ptr), sp, n, frames, C.c_void_p(out_ptr), C.c_void_p(peaks_ptr) if peaks_ptr else None, mem)
+
+    def process_frames_1(self, slot, src):
+        src = np.ascontiguousarray(src, dtype=np.float32)
+        out = np.full_like(src, np.nan)
+        self._check(self.lib.gas_process_frames_1(self.h, int(slot), _np_ptr(out), _np_ptr(src), src.shape[0]), "gas_process_frames_1")
+        return out
+
+    def mix_channel_1(self, slot, channel, src):
+        src = np.ascontiguousarray(src, dtype=np.float32)
+        out = np.full_like(src, np.nan)
+        self._check(self.lib.gas_mix_channel_1(self.h, int(slot), int(channel), _np_ptr(out), _np_ptr(src), src.shape[0]), "gas_mix_channel_1")
+        return out
+
+    def set_stream(self, hip_stream):
+        self._check(self.lib.gas_ctx_set_stream(self.h, C.c_void_p(hip_stream)), "gas_ctx_set_stream")
+
+    def synchronize(self):
+        self._check(self.lib.gas_ctx_synchronize(self.h), "gas_ctx_synchronize")
+
+    def profile_enable(self, on=True):
+        self._check(self.lib.gas_profile_enable(self.h, int(on)), "gas_profile_enable")
+
+    def profile_read(self, reset=True):
+        p = Profile()
+        self._check(self.lib.gas_profile_read(self.h, C.byref(p), int(reset)), "gas_profile_read")
+        return {"launches": p.launches, "kernel_ms": p.kernel_ms, "bytes_per_launch": p.bytes_per_launch, "kernel": p.kernel_name.decode()}

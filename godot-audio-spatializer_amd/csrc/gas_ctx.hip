@@ -1,0 +1,908 @@
+// gas_ctx.hip -- the C ABI of include/gas_amd.h: context, device-resident playback-data slots,
+// parameter publication, and the per-callback launch sequence that stands in for
+// AudioSpatializerInstance::_mix_from_playback_list (audio_spatializer.cpp:326-471).
+//
+// There is NO CPU fallback: every entry needs a HIP device and fails with GAS_ERR_NO_DEVICE /
+// GAS_ERR_DEVICE otherwise.
+#include <algorithm>
+#include <cstring>
+#include <new>
+
+#include "gas_internal.h"
+
+namespace {
+
+// Launch groups: sources of one callback that run the same kernel instantiation.
+enum gas_group_type {
+	G_3D_MIX = 0, // must stay first: only these write channel pairs > 0
+	G_3D_PROCESS,
+	G_FX_COPY,
+	G_FX_SHELF,
+	G_FX_HRTF,
+	G_FX_ER,
+	G_FX_ER_HRTF,
+	G_COUNT
+};
+
+const char *const k_group_kernel[G_COUNT] = {
+	"k_biquad_mix<MIX_CHANNEL>", "k_biquad_mix<PROCESS_FRAMES>", "k_biquad_mix<COPY>", "k_biquad_mix<FX_HIGHSHELF>",
+	"k_hrtf_ols", "k_er_only", "k_hrtf_ols<ER>"
+};
+
+struct SlotInfo {
+	uint8_t used = 0;
+	uint8_t kind = 0;
+	uint8_t group = 0;
+	uint8_t has_params = 0;
+	uint8_t pending_free = 0;
+	uint8_t dirty_state = 0; // state must be zeroed before reuse
+};
+
+struct Group {
+	uint32_t offset = 0, count = 0;
+};
+
+constexpr uint32_t PROFILE_EVENTS = 4096;
+
+} // namespace
+
+struct gas_ctx {
+	gas_config cfg{};
+	hipStream_t stream = nullptr;
+	bool own_stream = false;
+	uint32_t hist_len = 0;
+	gas_dev_state st{};
+	gas_hrtf_table tab{};
+	float2 *d_tw = nullptr;
+
+	std::vector<SlotInfo> slots;
+	std::vector<uint32_t> free_list;
+	std::vector<uint32_t> pending_free;
+	std::vector<uint32_t> stamp; // duplicate detection per block
+	uint32_t stamp_gen = 0;
+
+	std::mutex params_mu;
+	gas_params *h_params = nullptr; // pinned [max_sources], latest published value
+	std::vector<uint8_t> dirty_flag;
+	std::vector<uint32_t> dirty_list;
+	gas_params *h_upload = nullptr; // pinned
+	uint32_t *h_upload_slots = nullptr; // pinned
+	gas_params *d_upload = nullptr;
+	uint32_t *d_upload_slots = nullptr;
+
+	uint32_t *h_idx = nullptr; // pinned [2 * max_sources]: slots then rows, sorted by group
+	uint32_t *d_slots = nullptr, *d_rows = nullptr;
+	uint32_t cached_n = UINT32_MAX;
+	bool cached_identity_rows = true;
+	Group groups[G_COUNT];
+
+	gas_audio_frame *d_src = nullptr; // staging for GAS_MEM_HOST, lazily sized
+	size_t d_src_frames = 0;
+	gas_audio_frame *d_out = nullptr; // [C][F]
+	float *d_peaks = nullptr; // [max_sources][2]
+	float *d_partials = nullptr;
+	uint32_t partial_rows = 0; // rows per channel pair
+
+	// one-source compatibility path
+	uint32_t *d_one_slot = nullptr;
+
+	bool profiling = false;
+	std::vector<hipEvent_t> ev;
+	uint32_t ev_used = 0;
+	uint64_t prof_launches = 0;
+	double prof_ms = 0.0;
+	uint64_t prof_bytes = 0;
+	int prof_group = -1;
+
+	std::string last_err;
+};
+
+namespace {
+
+#define GAS_HIP(ctx, call)                                                                    \
+	do {                                                                                      \
+		hipError_t _e = (call);                                                               \
+		if (_e != hipSuccess) {                                                               \
+			(ctx)->last_err = std::string(#call) + ": " + hipGetErrorString(_e);              \
+			return GAS_ERR_DEVICE;                                                            \
+		}                                                                                     \
+	} while (0)
+
+int group_of(int kind, const int32_t *fx, uint32_t n_fx) {
+	if (kind == GAS_KIND_3D_MIX) {
+		return n_fx == 0 ? G_3D_MIX : -1;
+	}
+	if (kind == GAS_KIND_3D_PROCESS) {
+		return n_fx == 0 ? G_3D_PROCESS : -1;
+	}
+	if (kind != GAS_KIND_EFFECT) {
+		return -1;
+	}
+	if (n_fx == 0) {
+		return G_FX_COPY;
+	}
+	if (n_fx == 1 && fx[0] == GAS_FX_HIGHSHELF) {
+		return G_FX_SHELF;
+	}
+	if (n_fx == 1 && fx[0] == GAS_FX_HRTF) {
+		return G_FX_HRTF;
+	}
+	if (n_fx == 1 && fx[0] == GAS_FX_EARLY_REFLECTIONS) {
+		return G_FX_ER;
+	}
+	if (n_fx == 2 && fx[0] == GAS_FX_EARLY_REFLECTIONS && fx[1] == GAS_FX_HRTF) {
+		return G_FX_ER_HRTF;
+	}
+	return -2; // a chain without a fused kernel yet
+}
+
+uint32_t group_partials(int gt, uint32_t n) {
+	if (n == 0) {
+		return 0;
+	}
+	if (gt == G_FX_HRTF || gt == G_FX_ER || gt == G_FX_ER_HRTF) {
+		return gas_hrtf_partials(n, nullptr);
+	}
+	return gas_biquad_partials(n);
+}
+
+// B = N*F*8 + N*S + N*H + B_tab + C*F*8 (compulsory bytes of one launch group).
+uint64_t group_bytes(const gas_ctx *c, int gt, uint32_t n) {
+	const uint64_t F = c->cfg.frames;
+	uint64_t C = 1, S = 0, H = 0, tab = 0;
+	switch (gt) {
+		case G_3D_MIX:
+			C = c->cfg.channel_count;
+			S = C * 144 + 32 + 8; // 2 ears x (9 f32 r + 9 f32 w) per pair + params + peak
+			break;
+		case G_3D_PROCESS:
+		case G_FX_SHELF:
+			S = 144 + 32 + 8;
+			break;
+		case G_FX_COPY:
+			S = 8;
+			break;
+		case G_FX_HRTF:
+			S = 24; // gain + dir, previous gain r/w, peak
+			H = 2ull * c->hist_len * 4; // history read + write
+			tab = (uint64_t)c->tab.dirs * 2 * GAS_HRTF_TAPS * 4;
+			break;
+		case G_FX_ER:
+			S = 8 + 64 + 8;
+			H = (uint64_t)GAS_ER_TAPS * F * 8 + F * 8; // tap gathers + ring write
+			break;
+		case G_FX_ER_HRTF:
+			S = 24 + 64 + 8;
+			H = (uint64_t)GAS_ER_TAPS * F * 8 + F * 8 + 2ull * c->hist_len * 4;
+			tab = (uint64_t)c->tab.dirs * 2 * GAS_HRTF_TAPS * 4;
+			break;
+	}
+	return (uint64_t)n * (F * 8 + S + H) + tab + C * F * 8;
+}
+
+int ensure_partials(gas_ctx *c, uint32_t rows) {
+	if (rows <= c->partial_rows) {
+		return GAS_OK;
+	}
+	if (c->d_partials) {
+		GAS_HIP(c, hipStreamSynchronize(c->stream));
+		GAS_HIP(c, hipFree(c->d_partials));
+		c->d_partials = nullptr;
+		c->partial_rows = 0;
+	}
+	const size_t bytes = (size_t)rows * c->cfg.channel_count * c->cfg.frames * 2 * sizeof(float);
+	GAS_HIP(c, hipMalloc(&c->d_partials, bytes));
+	c->partial_rows = rows;
+	return GAS_OK;
+}
+
+// Device work of one callback over already-grouped entries.
+int run_groups(gas_ctx *c, const gas_audio_frame *d_src, const uint32_t *d_slots, const uint32_t *d_rows, const Group *groups, uint32_t n_total, gas_audio_frame *d_out, float *d_peaks, uint32_t channel_begin, uint32_t channel_count, int force_mode) {
+	const uint32_t F = c->cfg.frames;
+	uint32_t p_total = 0, p_mix = 0;
+	for (int gt = 0; gt < G_COUNT; gt++) {
+		p_total += group_partials(gt, groups[gt].count);
+		if (gt == G_3D_MIX) {
+			p_mix = p_total;
+		}
+	}
+	int rc = ensure_partials(c, p_total > 0 ? p_total : 1);
+	if (rc != GAS_OK) {
+		return rc;
+	}
+	if (n_total > 0) {
+		GAS_HIP(c, hipMemsetAsync(d_peaks, 0, (size_t)n_total * 2 * sizeof(float), c->stream));
+	}
+
+	// the dominant launch of this callback is the one timed by the profiler
+	int dom = -1;
+	for (int gt = 0; gt < G_COUNT; gt++) {
+		if (groups[gt].count > 0 && (dom < 0 || groups[gt].count > groups[dom].count)) {
+			dom = gt;
+		}
+	}
+
+	uint32_t p_off = 0;
+	for (int gt = 0; gt < G_COUNT; gt++) {
+		const Group &gr = groups[gt];
+		if (gr.count == 0) {
+			continue;
+		}
+		gas_group_args ga;
+		ga.src = d_src;
+		ga.rows = d_rows ? d_rows + gr.offset : nullptr;
+		ga.slots = d_slots + gr.offset;
+		ga.n = gr.count;
+		ga.peaks = d_peaks;
+		const bool timed = c->profiling && gt == dom && c->ev_used + 2 <= c->ev.size();
+		if (timed) {
+			GAS_HIP(c, hipEventRecord(c->ev[c->ev_used], c->stream));
+		}
+		hipError_t e = hipSuccess;
+		switch (gt) {
+			case G_3D_MIX:
+			case G_3D_PROCESS: {
+				int mode = gt == G_3D_MIX ? GAS_MODE_MIX_CHANNEL : GAS_MODE_PROCESS_FRAMES;
+				if (force_mode >= 0) {
+					mode = force_mode;
+				}
+				const uint32_t cb = mode == GAS_MODE_MIX_CHANNEL ? channel_begin : 0;
+				const uint32_t cc = mode == GAS_MODE_MIX_CHANNEL ? channel_count : 1;
+				e = gas_launch_biquad_mix(c->stream, mode, ga, c->st, F, cb, cc, c->cfg.mix_rate, c->d_partials, p_off, c->partial_rows);
+			} break;
+			case G_FX_COPY:
+				e = gas_launch_biquad_mix(c->stream, GAS_MODE_COPY, ga, c->st, F, 0, 1, c->cfg.mix_rate, c->d_partials, p_off, c->partial_rows);
+				break;
+			case G_FX_SHELF:
+				e = gas_launch_biquad_mix(c->stream, GAS_MODE_FX_HIGHSHELF, ga, c->st, F, 0, 1, c->cfg.mix_rate, c->d_partials, p_off, c->partial_rows);
+				break;
+			case G_FX_HRTF:
+				e = gas_launch_hrtf_ols(c->stream, false, ga, c->st, c->tab, c->d_tw, F, c->hist_len, c->cfg.er_ring_frames, c->d_partials, p_off, c->partial_rows);
+				break;
+			case G_FX_ER_HRTF:
+				e = gas_launch_hrtf_ols(c->stream, true, ga, c->st, c->tab, c->d_tw, F, c->hist_len, c->cfg.er_ring_frames, c->d_partials, p_off, c->partial_rows);
+				break;
+			case G_FX_ER:
+				e = gas_launch_er_only(c->stream, ga, c->st, F, c->cfg.er_ring_frames, c->d_partials, p_off, c->partial_rows);
+				break;
+		}
+		GAS_HIP(c, e);
+		if (timed) {
+			GAS_HIP(c, hipEventRecord(c->ev[c->ev_used + 1], c->stream));
+			c->ev_used += 2;
+			c->prof_bytes = group_bytes(c, gt, gr.count);
+			c->prof_group = gt;
+		}
+		p_off += group_partials(gt, gr.count);
+	}
+
+	// channel pair 0 sums every group's partials; pairs > 0 only the mix_channel group's (which come first)
+	GAS_HIP(c, gas_launch_mix_reduce(c->stream, c->d_partials, p_total, c->partial_rows, 1, F, d_out));
+	if (channel_count > 1) {
+		GAS_HIP(c, gas_launch_mix_reduce(c->stream, c->d_partials + (size_t)c->partial_rows * F * 2, p_mix, c->partial_rows, channel_count - 1, F, d_out + F));
+	}
+	return GAS_OK;
+}
+
+int flush_params(gas_ctx *c) {
+	uint32_t m = 0;
+	{
+		std::lock_guard<std::mutex> lk(c->params_mu);
+		m = (uint32_t)c->dirty_list.size();
+		for (uint32_t i = 0; i < m; i++) {
+			const uint32_t s = c->dirty_list[i];
+			c->h_upload[i] = c->h_params[s];
+			c->h_upload_slots[i] = s;
+			c->dirty_flag[s] = 0;
+		}
+		c->dirty_list.clear();
+	}
+	if (m == 0) {
+		return GAS_OK;
+	}
+	// the pinned upload buffers are reused next callback: the copies must have left the host first
+	GAS_HIP(c, hipMemcpyAsync(c->d_upload, c->h_upload, (size_t)m * sizeof(gas_params), hipMemcpyHostToDevice, c->stream));
+	GAS_HIP(c, hipMemcpyAsync(c->d_upload_slots, c->h_upload_slots, (size_t)m * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+	GAS_HIP(c, gas_launch_scatter_params(c->stream, c->st.params, c->d_upload, c->d_upload_slots, m));
+	GAS_HIP(c, hipStreamSynchronize(c->stream));
+	return GAS_OK;
+}
+
+int apply_pending_frees(gas_ctx *c) {
+	for (uint32_t s : c->pending_free) {
+		SlotInfo &si = c->slots[s];
+		si = SlotInfo{};
+		si.dirty_state = 1;
+		c->free_list.push_back(s);
+	}
+	if (!c->pending_free.empty()) {
+		c->pending_free.clear();
+		c->cached_n = UINT32_MAX;
+	}
+	return GAS_OK;
+}
+
+// Validate + counting-sort the callback's slot list by launch group.
+int build_groups(gas_ctx *c, const uint32_t *slots, uint32_t n) {
+	uint32_t counts[G_COUNT] = { 0 };
+	if (++c->stamp_gen == 0) {
+		std::fill(c->stamp.begin(), c->stamp.end(), 0u);
+		c->stamp_gen = 1;
+	}
+	for (uint32_t i = 0; i < n; i++) {
+		const uint32_t s = slots[i];
+		if (s >= c->cfg.max_sources || !c->slots[s].used) {
+			return GAS_ERR_BAD_SLOT;
+		}
+		if (!c->slots[s].has_params) {
+			return GAS_ERR_NO_PARAMS;
+		}
+		if (c->stamp[s] == c->stamp_gen) {
+			return GAS_ERR_INVALID_ARGUMENT; // one playback twice in a callback would race on its state
+		}
+		c->stamp[s] = c->stamp_gen;
+		counts[c->slots[s].group]++;
+	}
+	uint32_t off = 0, cursor[G_COUNT];
+	int nonempty = 0;
+	for (int gt = 0; gt < G_COUNT; gt++) {
+		c->groups[gt].offset = off;
+		c->groups[gt].count = counts[gt];
+		cursor[gt] = off;
+		off += counts[gt];
+		nonempty += counts[gt] > 0;
+	}
+	uint32_t *hs = c->h_idx, *hr = c->h_idx + c->cfg.max_sources;
+	for (uint32_t i = 0; i < n; i++) {
+		const uint32_t p = cursor[c->slots[slots[i]].group]++;
+		hs[p] = slots[i];
+		hr[p] = i;
+	}
+	c->cached_identity_rows = nonempty <= 1;
+	if (n > 0) {
+		GAS_HIP(c, hipMemcpyAsync(c->d_slots, hs, (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+		if (!c->cached_identity_rows) {
+			GAS_HIP(c, hipMemcpyAsync(c->d_rows, hr, (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+		}
+		GAS_HIP(c, hipStreamSynchronize(c->stream)); // h_idx is reused by the next list
+	}
+	c->cached_n = n;
+	return GAS_OK;
+}
+
+int needs_hrtf(const gas_ctx *c) {
+	return (c->groups[G_FX_HRTF].count > 0 || c->groups[G_FX_ER_HRTF].count > 0) && c->tab.spec == nullptr;
+}
+
+} // namespace
+
+extern "C" {
+
+int gas_abi_version(void) {
+	return GAS_ABI_VERSION;
+}
+
+const char *gas_strerror(int status) {
+	switch (status) {
+		case GAS_OK:
+			return "ok";
+		case GAS_ERR_INVALID_ARGUMENT:
+			return "invalid argument";
+		case GAS_ERR_OUT_OF_SLOTS:
+			return "no free source slot (max_sources reached)";
+		case GAS_ERR_BAD_SLOT:
+			return "slot is not allocated";
+		case GAS_ERR_FRAME_COUNT:
+			return "unexpected frame count (must equal the context's frames)";
+		case GAS_ERR_NO_HRTF:
+			return "an HRTF source was processed before gas_hrtf_load";
+		case GAS_ERR_UNSUPPORTED_CHAIN:
+			return "effect chain has no device kernel";
+		case GAS_ERR_DEVICE:
+			return "HIP runtime error (see gas_last_device_error)";
+		case GAS_ERR_NO_DEVICE:
+			return "no usable HIP device; this library has no CPU fallback";
+		case GAS_ERR_OUT_OF_MEMORY:
+			return "out of memory";
+		case GAS_ERR_KIND_MISMATCH:
+			return "operation does not apply to this source kind";
+		case GAS_ERR_BAD_CHANNEL:
+			return "unexpected channel";
+		case GAS_ERR_NO_PARAMS:
+			return "SpatializerParameters were never published for a source";
+		default:
+			return "unknown status";
+	}
+}
+
+const char *gas_last_device_error(gas_ctx *ctx) {
+	return ctx ? ctx->last_err.c_str() : "";
+}
+
+void gas_ctx_destroy(gas_ctx *c) {
+	if (!c) {
+		return;
+	}
+	(void)hipSetDevice(c->cfg.device);
+	if (c->stream) {
+		(void)hipStreamSynchronize(c->stream);
+	}
+	for (hipEvent_t e : c->ev) {
+		(void)hipEventDestroy(e);
+	}
+	(void)hipFree(c->st.bq);
+	(void)hipFree(c->st.hrtf_hist);
+	(void)hipFree(c->st.hrtf_prev_gain);
+	(void)hipFree(c->st.er_ring);
+	(void)hipFree(c->st.er_pos);
+	(void)hipFree(c->st.params);
+	(void)hipFree(c->tab.spec);
+	(void)hipFree(c->d_tw);
+	(void)hipFree(c->d_upload);
+	(void)hipFree(c->d_upload_slots);
+	(void)hipFree(c->d_slots);
+	(void)hipFree(c->d_rows);
+	(void)hipFree(c->d_src);
+	(void)hipFree(c->d_out);
+	(void)hipFree(c->d_peaks);
+	(void)hipFree(c->d_partials);
+	(void)hipFree(c->d_one_slot);
+	(void)hipHostFree(c->h_params);
+	(void)hipHostFree(c->h_upload);
+	(void)hipHostFree(c->h_upload_slots);
+	(void)hipHostFree(c->h_idx);
+	if (c->own_stream && c->stream) {
+		(void)hipStreamDestroy(c->stream);
+	}
+	delete c;
+}
+
+int gas_ctx_create(const gas_config *cfg, gas_ctx **out_ctx) {
+	if (!cfg || !out_ctx || cfg->struct_size != sizeof(gas_config)) {
+		return GAS_ERR_INVALID_ARGUMENT;
+	}
+	*out_ctx = nullptr;
+	if (cfg->max_sources == 0 || cfg->channel_count < 1 || cfg->channel_count > GAS_MAX_CHANNELS_PER_BUS || !(cfg->mix_rate > 0.0f)) {
+		return GAS_ERR_INVALID_ARGUMENT;
+	}
+	if (cfg->frames == 0 || cfg->frames > 512 || cfg->frames % 128 != 0) {
+		return GAS_ERR_FRAME_COUNT;
+	}
+	if (cfg->er_ring_frames != 0 && ((cfg->er_ring_frames & (cfg->er_ring_frames - 1)) != 0 || cfg->er_ring_frames < 2 * cfg->frames)) {
+		return GAS_ERR_INVALID_ARGUMENT;
+	}
+	int n_dev = 0;
+	if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0 || cfg->device < 0 || cfg->device >= n_dev) {
+		return GAS_ERR_NO_DEVICE;
+	}
+	gas_ctx *c = new (std::nothrow) gas_ctx();
+	if (!c) {
+		return GAS_ERR_OUT_OF_MEMORY;
+	}
+	c->cfg = *cfg;
+	c->hist_len = 512 - cfg->frames / 2;
+	const size_t N = cfg->max_sources;
+	int rc = [&]() -> int {
+		GAS_HIP(c, hipSetDevice(cfg->device));
+		GAS_HIP(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+		c->own_stream = true;
+		c->st.bq_stride = N * 8;
+		GAS_HIP(c, hipMalloc(&c->st.bq, sizeof(float) * GAS_BQ_FIELDS * c->st.bq_stride));
+		GAS_HIP(c, hipMemsetAsync(c->st.bq, 0, sizeof(float) * GAS_BQ_FIELDS * c->st.bq_stride, c->stream));
+		GAS_HIP(c, hipMalloc(&c->st.hrtf_hist, sizeof(float) * N * c->hist_len));
+		GAS_HIP(c, hipMemsetAsync(c->st.hrtf_hist, 0, sizeof(float) * N * c->hist_len, c->stream));
+		GAS_HIP(c, hipMalloc(&c->st.hrtf_prev_gain, sizeof(float) * N));
+		GAS_HIP(c, hipMemsetAsync(c->st.hrtf_prev_gain, 0, sizeof(float) * N, c->stream));
+		if (cfg->er_ring_frames) {
+			GAS_HIP(c, hipMalloc(&c->st.er_ring, sizeof(gas_audio_frame) * N * cfg->er_ring_frames));
+			GAS_HIP(c, hipMemsetAsync(c->st.er_ring, 0, sizeof(gas_audio_frame) * N * cfg->er_ring_frames, c->stream));
+			GAS_HIP(c, hipMalloc(&c->st.er_pos, sizeof(uint32_t) * N));
+			GAS_HIP(c, hipMemsetAsync(c->st.er_pos, 0, sizeof(uint32_t) * N, c->stream));
+		}
+		GAS_HIP(c, hipMalloc(&c->st.params, sizeof(gas_params) * N));
+		GAS_HIP(c, hipMemsetAsync(c->st.params, 0, sizeof(gas_params) * N, c->stream));
+		GAS_HIP(c, hipMalloc(&c->d_upload, sizeof(gas_params) * N));
+		GAS_HIP(c, hipMalloc(&c->d_upload_slots, sizeof(uint32_t) * N));
+		GAS_HIP(c, hipMalloc(&c->d_slots, sizeof(uint32_t) * N));
+		GAS_HIP(c, hipMalloc(&c->d_rows, sizeof(uint32_t) * N));
+		GAS_HIP(c, hipMalloc(&c->d_out, sizeof(gas_audio_frame) * cfg->channel_count * cfg->frames));
+		GAS_HIP(c, hipMalloc(&c->d_peaks, sizeof(float) * 2 * N));
+		GAS_HIP(c, hipMalloc(&c->d_one_slot, sizeof(uint32_t)));
+		GAS_HIP(c, hipHostMalloc(&c->h_params, sizeof(gas_params) * N, hipHostMallocDefault));
+		GAS_HIP(c, hipHostMalloc(&c->h_upload, sizeof(gas_params) * N, hipHostMallocDefault));
+		GAS_HIP(c, hipHostMalloc(&c->h_upload_slots, sizeof(uint32_t) * N, hipHostMallocDefault));
+		GAS_HIP(c, hipHostMalloc(&c->h_idx, sizeof(uint32_t) * 2 * N, hipHostMallocDefault));
+		float2 h_tw[64 * 16];
+		gas_make_twiddles(h_tw);
+		GAS_HIP(c, hipMalloc(&c->d_tw, sizeof(h_tw)));
+		GAS_HIP(c, hipMemcpyAsync(c->d_tw, h_tw, sizeof(h_tw), hipMemcpyHostToDevice, c->stream));
+		GAS_HIP(c, hipStreamSynchronize(c->stream));
+		return GAS_OK;
+	}();
+	if (rc != GAS_OK) {
+		gas_ctx_destroy(c);
+		return rc;
+	}
+	c->slots.resize(N);
+	c->stamp.assign(N, 0);
+	c->dirty_flag.assign(N, 0);
+	c->free_list.reserve(N);
+	for (size_t s = N; s-- > 0;) {
+		c->free_list.push_back((uint32_t)s); // pop_back hands out 0, 1, 2, ...
+	}
+	*out_ctx = c;
+	return GAS_OK;
+}
+
+int gas_ctx_set_stream(gas_ctx *c, void *hip_stream) {
+	if (!c) {
+		return GAS_ERR_INVALID_ARGUMENT;
+	}
+	GAS_HIP(c, hipSetDevice(c->cfg.device));
+	GAS_HIP(c, hipStreamSynchronize(c->stream));
+	if (c->own_stream) {
+		GAS_HIP(c, hipStreamDestroy(c->stream));
+		c->own_stream = false;
+	}
+	c->stream = reinterpret_cast<hipStream_t>(hip_stream);
+	return GAS_OK;
+}
+
+int gas_ctx_synchronize(gas_ctx *c) {
+	if (!c) {
+		return GAS_ERR_INVALID_ARGUMENT;
+	}
+	GAS_HIP(c, hipStreamSynchronize(c->stream));
+	return GAS_OK;
+}
+
+int gas_source_alloc(gas_ctx *c, int kind, const int32_t *effects, uint32_t n_effects, uint32_t *out_slot) {
+	if (!c || !out_slot || n_effects > GAS_MAX_EFFECTS || (n_effects > 0 && !effects)) {
+		return GAS_ERR_INVALID_ARGUMENT;
+	}
+	const int g = group_of(kind, effects, n_effects);
+	if (g == -1) {
+		return GAS_ERR_INVALID_ARGUMENT;
+	}
+	if (g == -2) {
+		return GAS_ERR_UNSUPPORTED_CHAIN;
+	}
+	if ((g == G_FX_ER || g == G_FX_ER_HRTF) && c->cfg.er_ring_frames == 0) {
+		return GAS_ERR_UNSUPPORTED_CHAIN;
+	}
+	if (c->free_list.empty()) {
+		return GAS_ERR_OUT_OF_SLOTS;
+	}
+	const uint32_t s = c->free_list.back();
+	if (c->slots[s].dirty_state) {
+		GAS_HIP(c, hipSetDevice(c->cfg.device));
+		GAS_HIP(c, gas_launch_zero_slot(c->stream, c->st, s, c->hist_len, c->cfg.er_ring_frames));
+	}
+	c->free_list.pop_back();
+	SlotInfo si;
+	si.used = 1;
+	si.kind = (uint8_t)kind;
+	si.group = (uint8_t)g;
+	c->slots[s] = si;
+	*out_slot = s;
+	return GAS_OK;
+}
+
+int gas_source_free(gas_ctx *c, uint32_t slot) {
+	if (!c) {
+		return GAS_ERR_INVALID_ARGUMENT;
+	}
+	if (slot >= c->cfg.max_sources || !c->slots[slot].used || c->slots[slot].pending_free) {
+		return GAS_ERR_BAD_SLOT;
+	}
+	// deferred like audio_spatializer.cpp:538-547: the audio thread may still name it this callback
+	c->slots[slot].pending_free = 1;
+	c->pending_free.push_back(slot);
+	return GAS_OK;
+}
+
+int gas_source_reset(gas_ctx *c, uint32_t slot) {
+	if (!c) {
+		return GAS_ERR_INVALID_ARGUMENT;
+	}
+	if (slot >= c->cfg.max_sources || !c->slots[slot].used) {
+		return GAS_ERR_BAD_SLOT;
+	}
+	GAS_HIP(c, hipSetDevice(c->cfg.device));
+	GAS_HIP(c, gas_launch_zero_slot(c->stream, c->st, slot, c->hist_len, c->cfg.er_ring_frames));
+	return GAS_OK;
+}
+
+int gas_params_publish(gas_ctx *c, uint32_t slot, const gas_params *params) {
+	if (!c || !params) {
+		return GAS_ERR_INVALID_ARGUMENT;
+	}
+	if (slot >= c->cfg.max_sources || !c->slots[slot].used) {
+		return GAS_ERR_BAD_SLOT;
+	}
+	std::lock_guard<std::mutex> lk(c->params_mu);
+	c->h_params[slot] = *params;
+	if (!c->dirty_flag[slot]) {
+		c->dirty_flag[slot] = 1;
+		c->dirty_list.push_back(slot);
+	}
+	c->slots[slot].has_params = 1;
+	return GAS_OK;
+}
+
+int gas_params_publish_batch(gas_ctx *c, const uint32_t *slots, const gas_params *params, uint32_t n, int params_mem) {
+	if (!c || !params || (params_mem != GAS_MEM_HOST && params_mem != GAS_MEM_DEVICE)) {
+		return GAS_ERR_INVALID_ARGUMENT;
+	}
+	if (params_mem == GAS_MEM_HOST) {
+		if (!slots) {
+			return GAS_ERR_INVALID_ARGUMENT;
+		}
+		for (uint32_t i = 0; i < n; i++) {
+			if (slots[i] >= c->cfg.max_sources || !c->slots[slots[i]].used) {
+				return GAS_ERR_BAD_SLOT;
+			}
+		}
+		std::lock_guard<std::mutex> lk(c->params_mu);
+		for (uint32_t i = 0; i < n; i++) {
+			const uint32_t s = slots[i];
+			c->h_params[s] = params[i];
+			if (!c->dirty_flag[s]) {
+				c->dirty_flag[s] = 1;
+				c->dirty_list.push_back(s);
+			}
+			c->slots[s].has_params = 1;
+		}
+		return GAS_OK;
+	}
+	// Device-resident parameter rows (e.g. produced by a parameter kernel): scatter on the stream.
+	// slots == NULL addresses the slot list of the last gas_process_block, in its row order
+	// when that list was one launch group.
+	GAS_HIP(c, hipSetDevice(c->cfg.device));
+	if (slots) {
+		if (n > c->cfg.max_sources) {
+			return GAS_ERR_INVALID_ARGUMENT;
+		}
+		for (uint32_t i = 0; i < n; i++) {
+			if (slots[i] >= c->cfg.max_sources || !c->slots[slots[i]].used) {
+				return GAS_ERR_BAD_SLOT;
+			}
+			c->slots[slots[i]].has_params = 1;
+		}
+		std::memcpy(c->h_upload_slots, slots, (size_t)n * sizeof(uint32_t));
+		GAS_HIP(c, hipMemcpyAsync(c->d_upload_slots, c->h_upload_slots, (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+		GAS_HIP(c, gas_launch_scatter_params(c->stream, c->st.params, params, c->d_upload_slots, n));
+		GAS_HIP(c, hipStreamSynchronize(c->stream));
+	} else {
+		if (c->cached_n != n || !c->cached_identity_rows) {
+			return GAS_ERR_INVALID_ARGUMENT;
+		}
+		GAS_HIP(c, gas_launch_scatter_params(c->stream, c->st.params, params, c->d_slots, n));
+	}
+	return GAS_OK;
+}
+
+int gas_hrtf_load(gas_ctx *c, const float *hrir, uint32_t dirs, uint32_t taps) {
+	if (!c || !hrir || dirs == 0 || taps == 0 || taps > GAS_HRTF_TAPS) {
+		return GAS_ERR_INVALID_ARGUMENT;
+	}
+	GAS_HIP(c, hipSetDevice(c->cfg.device));
+	GAS_HIP(c, hipStreamSynchronize(c->stream));
+	if (c->tab.spec) {
+		GAS_HIP(c, hipFree(c->tab.spec));
+		c->tab.spec = nullptr;
+		c->tab.dirs = 0;
+	}
+	float *d_hrir = nullptr;
+	const size_t bytes = (size_t)dirs * 2 * taps * sizeof(float);
+	GAS_HIP(c, hipMalloc(&d_hrir, bytes));
+	int rc = [&]() -> int {
+		GAS_HIP(c, hipMemcpyAsync(d_hrir, hrir, bytes, hipMemcpyHostToDevice, c->stream));
+		GAS_HIP(c, hipMalloc(&c->tab.spec, (size_t)dirs * 8 * 64 * sizeof(float4)));
+		GAS_HIP(c, gas_launch_hrtf_table(c->stream, d_hrir, dirs, taps, c->d_tw, c->tab.spec));
+		GAS_HIP(c, hipStreamSynchronize(c->stream));
+		return GAS_OK;
+	}();
+	(void)hipFree(d_hrir);
+	if (rc == GAS_OK) {
+		c->tab.dirs = dirs;
+	}
+	return rc;
+}
+
+int gas_process_block(gas_ctx *c, const gas_audio_frame *src, const uint32_t *slots, uint32_t n, uint32_t frames, gas_audio_frame *out, float *peaks, int mem) {
+	if (!c || !out || (mem != GAS_MEM_HOST && mem != GAS_MEM_DEVICE) || (n > 0 && !src) || n > c->cfg.max_sources) {
+		return GAS_ERR_INVALID_ARGUMENT;
+	}
+	const uint32_t F = c->cfg.frames, C = c->cfg.channel_count;
+	const size_t out_bytes = (size_t)C * F * sizeof(gas_audio_frame);
+	int rc = GAS_OK;
+	auto fail = [&](int code) {
+		if (mem == GAS_MEM_HOST) {
+			std::memset(out, 0, out_bytes); // the reference's ERR_FAIL paths leave a zeroed mix (:335-343)
+		}
+		return code;
+	};
+	if (frames != F) {
+		return fail(GAS_ERR_FRAME_COUNT);
+	}
+	if (hipSetDevice(c->cfg.device) != hipSuccess) {
+		return fail(GAS_ERR_NO_DEVICE);
+	}
+	apply_pending_frees(c);
+	if (slots) {
+		rc = build_groups(c, slots, n);
+		if (rc != GAS_OK) {
+			c->cached_n = UINT32_MAX;
+			return fail(rc);
+		}
+	} else if (c->cached_n != n) {
+		return fail(GAS_ERR_INVALID_ARGUMENT);
+	}
+	if (needs_hrtf(c)) {
+		return fail(GAS_ERR_NO_HRTF);
+	}
+	rc = flush_params(c); // one snapshot per callback (audio_spatializer.cpp:328)
+	if (rc != GAS_OK) {
+		return fail(rc);
+	}
+
+	const gas_audio_frame *d_src = src;
+	gas_audio_frame *d_out = out;
+	float *d_peaks = peaks ? peaks : c->d_peaks;
+	if (mem == GAS_MEM_HOST) {
+		const size_t need = (size_t)n * F;
+		if (need > c->d_src_frames) {
+			if (c->d_src) {
+				(void)hipFree(c->d_src);
+				c->d_src = nullptr;
+				c->d_src_frames = 0;
+			}
+			if (hipMalloc(&c->d_src, need * sizeof(gas_audio_frame)) != hipSuccess) {
+				return fail(GAS_ERR_OUT_OF_MEMORY);
+			}
+			c->d_src_frames = need;
+		}
+		if (n > 0) {
+			hipError_t e = hipMemcpyAsync(c->d_src, src, need * sizeof(gas_audio_frame), hipMemcpyHostToDevice, c->stream);
+			if (e != hipSuccess) {
+				c->last_err = hipGetErrorString(e);
+				return fail(GAS_ERR_DEVICE);
+			}
+		}
+		d_src = c->d_src;
+		d_out = c->d_out;
+		d_peaks = c->d_peaks;
+	}
+	rc = run_groups(c, d_src, c->d_slots, c->cached_identity_rows ? nullptr : c->d_rows, c->groups, n, d_out, d_peaks, 0, C, -1);
+	if (rc != GAS_OK) {
+		return fail(rc);
+	}
+	if (mem == GAS_MEM_HOST) {
+		hipError_t e = hipMemcpyAsync(out, c->d_out, out_bytes, hipMemcpyDeviceToHost, c->stream);
+		if (e == hipSuccess && peaks && n > 0) {
+			e = hipMemcpyAsync(peaks, c->d_peaks, (size_t)n * 2 * sizeof(float), hipMemcpyDeviceToHost, c->stream);
+		}
+		if (e == hipSuccess) {
+			e = hipStreamSynchronize(c->stream);
+		}
+		if (e != hipSuccess) {
+			c->last_err = hipGetErrorString(e);
+			return fail(GAS_ERR_DEVICE);
+		}
+	}
+	return GAS_OK;
+}
+
+static int process_one(gas_ctx *c, uint32_t slot, int channel, bool mix_channel, gas_audio_frame *out, const gas_audio_frame *src, int frame_count) {
+	if (!c || !out || !src) {
+		return GAS_ERR_INVALID_ARGUMENT;
+	}
+	const uint32_t F = c->cfg.frames;
+	if (frame_count < 0 || (uint32_t)frame_count != F) {
+		return GAS_ERR_FRAME_COUNT;
+	}
+	if (slot >= c->cfg.max_sources || !c->slots[slot].used) {
+		return GAS_ERR_BAD_SLOT;
+	}
+	const SlotInfo &si = c->slots[slot];
+	if (!si.has_params) {
+		return GAS_ERR_NO_PARAMS;
+	}
+	const bool is3d = si.kind == GAS_KIND_3D_MIX || si.kind == GAS_KIND_3D_PROCESS;
+	if (mix_channel) {
+		if (!is3d) {
+			return GAS_ERR_KIND_MISMATCH;
+		}
+		if (channel < 0 || channel >= GAS_MAX_CHANNELS_PER_BUS) { // ERR_FAIL_INDEX_V(p_channel, 4, nullptr), audio_spatializer_3d.cpp:888
+			return GAS_ERR_BAD_CHANNEL;
+		}
+	}
+	GAS_HIP(c, hipSetDevice(c->cfg.device));
+	Group groups[G_COUNT];
+	int gt = si.group;
+	int force_mode = -1;
+	if (is3d) {
+		gt = G_3D_MIX;
+		force_mode = mix_channel ? GAS_MODE_MIX_CHANNEL : GAS_MODE_PROCESS_FRAMES;
+	}
+	groups[gt].offset = 0;
+	groups[gt].count = 1;
+	if ((gt == G_FX_HRTF || gt == G_FX_ER_HRTF) && c->tab.spec == nullptr) {
+		return GAS_ERR_NO_HRTF;
+	}
+	int rc = flush_params(c);
+	if (rc != GAS_OK) {
+		return rc;
+	}
+	if (c->d_src_frames < F) {
+		if (c->d_src) {
+			(void)hipFree(c->d_src);
+			c->d_src = nullptr;
+			c->d_src_frames = 0;
+		}
+		GAS_HIP(c, hipMalloc(&c->d_src, (size_t)F * sizeof(gas_audio_frame)));
+		c->d_src_frames = F;
+	}
+	GAS_HIP(c, hipMemcpyAsync(c->d_one_slot, &slot, sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+	GAS_HIP(c, hipMemcpyAsync(c->d_src, src, (size_t)F * sizeof(gas_audio_frame), hipMemcpyHostToDevice, c->stream));
+	rc = run_groups(c, c->d_src, c->d_one_slot, nullptr, groups, 1, c->d_out, c->d_peaks, mix_channel ? (uint32_t)channel : 0, 1, force_mode);
+	if (rc != GAS_OK) {
+		return rc;
+	}
+	GAS_HIP(c, hipMemcpyAsync(out, c->d_out, (size_t)F * sizeof(gas_audio_frame), hipMemcpyDeviceToHost, c->stream));
+	GAS_HIP(c, hipStreamSynchronize(c->stream));
+	return GAS_OK;
+}
+
+int gas_process_frames_1(gas_ctx *c, uint32_t slot, gas_audio_frame *out, const gas_audio_frame *src, int frame_count) {
+	return process_one(c, slot, 0, false, out, src, frame_count);
+}
+
+int gas_mix_channel_1(gas_ctx *c, uint32_t slot, int channel, gas_audio_frame *out, const gas_audio_frame *src, int frame_count) {
+	return process_one(c, slot, channel, true, out, src, frame_count);
+}
+
+int gas_profile_enable(gas_ctx *c, int on) {
+	if (!c) {
+		return GAS_ERR_INVALID_ARGUMENT;
+	}
+	GAS_HIP(c, hipSetDevice(c->cfg.device));
+	if (on && c->ev.empty()) {
+		c->ev.resize(PROFILE_EVENTS);
+		for (hipEvent_t &e : c->ev) {
+			GAS_HIP(c, hipEventCreate(&e));
+		}
+	}
+	c->profiling = on != 0;
+	return GAS_OK;
+}
+
+int gas_profile_read(gas_ctx *c, gas_profile *out, int reset) {
+	if (!c || !out) {
+		return GAS_ERR_INVALID_ARGUMENT;
+	}
+	GAS_HIP(c, hipSetDevice(c->cfg.device));
+	GAS_HIP(c, hipStreamSynchronize(c->stream));
+	for (uint32_t i = 0; i + 1 < c->ev_used; i += 2) {
+		float ms = 0.0f;
+		GAS_HIP(c, hipEventElapsedTime(&ms, c->ev[i], c->ev[i + 1]));
+		c->prof_ms += ms;
+		c->prof_launches++;
+	}
+	c->ev_used = 0;
+	std::memset(out, 0, sizeof(*out));
+	out->launches = c->prof_launches;
+	out->kernel_ms = c->prof_ms;
+	out->bytes_per_launch = c->prof_bytes;
+	if (c->prof_group >= 0) {
+		std::strncpy(out->kernel_name, k_group_kernel[c->prof_group], sizeof(out->kernel_name) - 1);
+	}
+	if (reset) {
+		c->prof_launches = 0;
+		c->prof_ms = 0.0;
+	}
+	return GAS_OK;
+}
+
+} // extern "C"

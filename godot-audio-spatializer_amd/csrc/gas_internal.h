@@ -1,0 +1,71 @@
+// gas_internal.h -- context layout and kernel launchers shared by the csrc/ translation units.
+// Not part of the ABI (include/gas_amd.h is).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/gas_amd.h"
+
+static_assert(sizeof(gas_params) == 128, "gas_params is a 128-byte POD");
+static_assert(sizeof(gas_audio_frame) == 8, "AudioFrame is 2 x f32");
+
+// ---------------------------------------------------------------------------
+// Device-resident SpatializerPlaybackData (audio_spatializer_3d.h:85-99,
+// audio_spatializer_effect.h:68-76), struct-of-arrays by "stream":
+//   stream = (slot * 4 + channel_pair) * 2 + ear      (audio_spatializer_3d.cpp:887-894)
+// so a wave of consecutive slots reads every field coalesced.
+// ---------------------------------------------------------------------------
+enum { GAS_BQ_FIELDS = 10 }; // b0 b1 b2 a1 a2 ha1 ha2 hb1 hb2 prev_vol
+enum { BQ_B0 = 0, BQ_B1, BQ_B2, BQ_A1, BQ_A2, BQ_HA1, BQ_HA2, BQ_HB1, BQ_HB2, BQ_PREV };
+
+struct gas_dev_state {
+	float *bq; // [GAS_BQ_FIELDS][max_sources * 8]
+	size_t bq_stride; // max_sources * 8
+	float *hrtf_hist; // [max_sources][hist_len]   gained mono history
+	float *hrtf_prev_gain; // [max_sources]
+	gas_audio_frame *er_ring; // [max_sources][er_ring_frames]
+	uint32_t *er_pos; // [max_sources]
+	gas_params *params; // [max_sources]
+};
+
+// What a launch group (one kind/chain) needs.
+struct gas_group_args {
+	const gas_audio_frame *src; // [n_rows_total][F]
+	const uint32_t *rows; // [n] row of src per group entry, or nullptr (= identity)
+	const uint32_t *slots; // [n] slot per group entry
+	uint32_t n;
+	float *peaks; // [n_rows_total][2]
+};
+
+enum gas_biquad_mode {
+	GAS_MODE_MIX_CHANNEL = 0, // audio_spatializer_3d.cpp:554-609
+	GAS_MODE_PROCESS_FRAMES = 1, // audio_spatializer_3d.cpp:491-552
+	GAS_MODE_FX_HIGHSHELF = 2, // [ENGINE] AudioEffectFilterInstance::process, 1 stage
+	GAS_MODE_COPY = 3, // empty effect chain, audio_spatializer_effect.cpp:41-46
+};
+
+struct gas_hrtf_table {
+	float4 *spec; // [dirs][8][64] = (HL.re, HL.im, HR.re, HR.im) of bin lane + 64 j, pre-scaled by 1/512
+	uint32_t dirs;
+};
+
+// Launchers (each only enqueues on `stream`; geometry is validated by the caller).
+// Returns the number of partial mixes (per channel) it writes into `partials`
+// ([C][P][F*2] floats, row stride P_stride).
+uint32_t gas_biquad_partials(uint32_t n); // P for n sources
+hipError_t gas_launch_biquad_mix(hipStream_t stream, int mode, const gas_group_args &g, const gas_dev_state &st, uint32_t frames, uint32_t channel_begin, uint32_t channel_count, float mix_rate, float *partials, uint32_t p_offset, uint32_t p_stride);
+
+uint32_t gas_hrtf_partials(uint32_t n, uint32_t *sources_per_wave);
+hipError_t gas_launch_hrtf_ols(hipStream_t stream, bool with_er, const gas_group_args &g, const gas_dev_state &st, const gas_hrtf_table &tab, const float2 *twiddles, uint32_t frames, uint32_t hist_len, uint32_t er_ring_frames, float *partials, uint32_t p_offset, uint32_t p_stride);
+hipError_t gas_launch_er_only(hipStream_t stream, const gas_group_args &g, const gas_dev_state &st, uint32_t frames, uint32_t er_ring_frames, float *partials, uint32_t p_offset, uint32_t p_stride);
+
+hipError_t gas_launch_hrtf_table(hipStream_t stream, const float *d_hrir, uint32_t dirs, uint32_t taps, const float2 *twiddles, float4 *spec);
+void gas_make_twiddles(float2 *host_tw /* [64][16] */);
+
+hipError_t gas_launch_mix_reduce(hipStream_t stream, const float *partials, uint32_t p_count, uint32_t p_stride, uint32_t channels, uint32_t frames, gas_audio_frame *out);
+hipError_t gas_launch_scatter_params(hipStream_t stream, gas_params *table, const gas_params *upload, const uint32_t *slots, uint32_t n);
+hipError_t gas_launch_zero_slot(hipStream_t stream, const gas_dev_state &st, uint32_t slot, uint32_t hist_len, uint32_t er_ring_frames);

@@ -1,0 +1,303 @@
+// k_biquad_mix.hip -- pan/attenuation volume ramp + time-varying high-shelf biquad for every
+// source of a callback, and the per-workgroup partial of the N-source -> stereo sum.
+//
+// Replaces, for all sources at once:
+//   AudioSpatializerInstance3D::mix_channel     audio_spatializer_3d.cpp:554-609   (GAS_MODE_MIX_CHANNEL)
+//   AudioSpatializerInstance3D::process_frames  audio_spatializer_3d.cpp:491-552   (GAS_MODE_PROCESS_FRAMES)
+//   [ENGINE] AudioEffectFilterInstance::process (high-shelf, 1 stage) as the single effect of an
+//   AudioSpatializerEffect chain, audio_spatializer_effect.cpp:52-76             (GAS_MODE_FX_HIGHSHELF)
+//   the empty-chain copy, audio_spatializer_effect.cpp:41-46                       (GAS_MODE_COPY)
+//   the accumulate + per-source peak of _mix_from_playback_list, audio_spatializer.cpp:432-444,449-461
+//
+// Geometry (CDNA4, wave64): one 64-lane workgroup = 32 sources x 2 ears; every lane owns one
+// serial recurrence (the biquad is a dependent chain over the F frames).
+// The 4 KiB-strided source rows are staged through LDS in [32 sources x 16 frames] tiles with
+// coalesced 16-byte loads (8 lanes cover one 128-byte line of one row), double-buffered against the
+// recurrence.  After each tile the wave switches roles: lane (half, frame, ear) sums the tile's 32
+// outputs over sources in fixed order and lanes 0..31 store 128 contiguous bytes of this
+// workgroup's partial mix.  No atomics in the sum: k_mix_reduce adds the partials in fixed order.
+//
+// Bound: HBM once N is large (algorithmic bytes/source = F*8 source + 80 state r/w + 128 params + 8 peak);
+// at N = 256 it is latency-bound on the F-step recurrence (8 waves on a 256-CU part) -- DESIGN.md.
+#include "gas_internal.h"
+
+namespace {
+
+constexpr int SRC_PER_WG = 32;
+constexpr int KF = 16; // frames per staged tile
+constexpr int ROW = 34; // LDS row stride in floats: 32 + 2 pad -> (34*sl + ear) % 32 distinct over a half-wave
+
+struct Coeffs {
+	float b0, b1, b2, a1, a2;
+};
+
+// [ENGINE] AudioFilterSW::prepare_coefficients, HIGHSHELF, resonance 1, stages 1:
+// f64 arithmetic, members stored f32 before the division by a0, feedback terms negated.
+__device__ inline Coeffs highshelf_coeffs(float sampling_rate, float cutoff_hz, float gain_lin) {
+	int sr_limit = (int)(sampling_rate / 2) + 512;
+	double final_cutoff = ((double)cutoff_hz > sr_limit) ? (double)sr_limit : (double)cutoff_hz;
+	if (final_cutoff < 1) {
+		final_cutoff = 1;
+	}
+	double omega = 6.2831853071795864769252867666 * final_cutoff / (double)sampling_rate;
+	double sin_v = sin(omega);
+	double cos_v = cos(omega);
+	double A = gain_lin;
+	if (A < 0.001) {
+		A = 0.001;
+	}
+	double beta = sqrt(A); // sqrt(Q) = 1
+	double a0 = (A + 1.0) - (A - 1.0) * cos_v + beta * sin_v;
+	Coeffs c;
+	c.b0 = (float)(A * ((A + 1.0) + (A - 1.0) * cos_v + beta * sin_v));
+	c.b1 = (float)(-2.0 * A * ((A - 1.0) + (A + 1.0) * cos_v));
+	c.b2 = (float)(A * ((A + 1.0) + (A - 1.0) * cos_v - beta * sin_v));
+	c.a1 = (float)(2.0 * ((A - 1.0) - (A + 1.0) * cos_v));
+	c.a2 = (float)((A + 1.0) - (A - 1.0) * cos_v - beta * sin_v);
+	c.b0 = (float)((double)c.b0 / a0);
+	c.b1 = (float)((double)c.b1 / a0);
+	c.b2 = (float)((double)c.b2 / a0);
+	c.a1 = (float)((double)c.a1 / (0.0 - a0));
+	c.a2 = (float)((double)c.a2 / (0.0 - a0));
+	return c;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(64) void k_biquad_mix(gas_group_args g, gas_dev_state st, uint32_t F, uint32_t c0, float mix_rate, float *__restrict__ partials, uint32_t p_offset, uint32_t p_stride) {
+	__shared__ float tile[2][SRC_PER_WG * ROW];
+
+	const int lane = threadIdx.x;
+	const int ear = lane & 1;
+	const int sl = lane >> 1;
+	const uint32_t c = c0 + blockIdx.y;
+	const uint32_t e = blockIdx.x * SRC_PER_WG + sl;
+	const bool valid = e < g.n;
+	const uint32_t ec = valid ? e : g.n - 1;
+	const uint32_t slot = g.slots[ec];
+	const uint32_t row = g.rows ? g.rows[ec] : ec;
+	const gas_params *P = st.params + slot;
+
+	// Row base of each of this lane's 4 staging loads per tile: load q covers tile element
+	// idx = q*64 + lane -> source idx>>3, 16-byte part idx&7.
+	const float *ld_base[4];
+#pragma unroll
+	for (int q = 0; q < 4; q++) {
+		int idx = q * 64 + lane;
+		uint32_t le = blockIdx.x * SRC_PER_WG + (idx >> 3);
+		le = le < g.n ? le : g.n - 1;
+		uint32_t lrow = g.rows ? g.rows[le] : le;
+		ld_base[q] = reinterpret_cast<const float *>(g.src) + (size_t)lrow * F * 2 + (idx & 7) * 4;
+	}
+
+	// ---- per-lane DSP state (SpatializerPlaybackData3D, audio_spatializer_3d.h:85-99) ----
+	const size_t stream = ((size_t)slot * 4 + c) * 2 + ear;
+	float *bq = st.bq;
+	const size_t bs = st.bq_stride;
+	Coeffs co = { 0, 0, 0, 0, 0 }, inc = { 0, 0, 0, 0, 0 };
+	float ha1 = 0, ha2 = 0, hb1 = 0, hb2 = 0;
+	float vs = 0, vf = 0;
+	bool filt = false;
+
+	if constexpr (MODE != GAS_MODE_COPY) {
+		co.b0 = bq[BQ_B0 * bs + stream];
+		co.b1 = bq[BQ_B1 * bs + stream];
+		co.b2 = bq[BQ_B2 * bs + stream];
+		co.a1 = bq[BQ_A1 * bs + stream];
+		co.a2 = bq[BQ_A2 * bs + stream];
+		ha1 = bq[BQ_HA1 * bs + stream];
+		ha2 = bq[BQ_HA2 * bs + stream];
+		hb1 = bq[BQ_HB1 * bs + stream];
+		hb2 = bq[BQ_HB2 * bs + stream];
+	}
+	if constexpr (MODE == GAS_MODE_MIX_CHANNEL || MODE == GAS_MODE_PROCESS_FRAMES) {
+		vs = bq[BQ_PREV * bs + stream]; // get_prev_mix_volume(c), (0,0) when never set (:880-885)
+		const float vs_other = bq[BQ_PREV * bs + (stream ^ 1)];
+		const float gain = P->linear_attenuation;
+		filt = (double)gain >= 0.001; // :503 / :568
+		if (filt) {
+			const Coeffs target = highshelf_coeffs(mix_rate, P->attenuation_filter_cutoff_hz, gain);
+			if (vs == 0 && vs_other == 0) { // is_just_started -> clear_history (:518-521, :583-587)
+				ha1 = ha2 = hb1 = hb2 = 0;
+			}
+			// [ENGINE] update_coeffs(F): ramp from the current coefficients to the target.
+			const int Fi = (int)F;
+			inc.a1 = (target.a1 - co.a1) / Fi;
+			inc.a2 = (target.a2 - co.a2) / Fi;
+			inc.b0 = (target.b0 - co.b0) / Fi;
+			inc.b1 = (target.b1 - co.b1) / Fi;
+			inc.b2 = (target.b2 - co.b2) / Fi;
+		}
+		if constexpr (MODE == GAS_MODE_MIX_CHANNEL) {
+			vf = P->mix_volumes[c][ear]; // :565
+		} else {
+			// prev_mix_volume(0) = the channel pair holding the largest component (:537-551)
+			float max_volume = 0.0f;
+			int max_index = 0;
+#pragma unroll
+			for (int i = 0; i < GAS_MAX_CHANNELS_PER_BUS; i++) {
+				if (P->mix_volumes[i][0] > max_volume) {
+					max_volume = P->mix_volumes[i][0];
+					max_index = i;
+				}
+				if (P->mix_volumes[i][1] > max_volume) {
+					max_volume = P->mix_volumes[i][1];
+					max_index = i;
+				}
+			}
+			vf = P->mix_volumes[max_index][ear];
+		}
+	}
+	if constexpr (MODE == GAS_MODE_FX_HIGHSHELF) {
+		co = highshelf_coeffs(mix_rate, P->fx_shelf_cutoff_hz, P->fx_shelf_gain); // coefficients snap every call
+		filt = true;
+	}
+
+	const bool all_filt = __all(filt || !valid);
+	const bool f_pow2 = (F & (F - 1)) == 0;
+	const float Ff = (float)(int)F;
+	const float invF = 1.0f / Ff;
+	float peak = 0.0f;
+
+	const uint32_t n_tiles = F / KF;
+	float4 pre[4];
+#pragma unroll
+	for (int q = 0; q < 4; q++) {
+		pre[q] = *reinterpret_cast<const float4 *>(ld_base[q]);
+	}
+
+	float *my_partial = partials + ((size_t)blockIdx.y * p_stride + p_offset + blockIdx.x) * (size_t)F * 2;
+
+	for (uint32_t tl = 0; tl < n_tiles; tl++) {
+		float *tb = tile[tl & 1];
+		// registers -> LDS (two 8-byte stores; rows are 136 B so 16-byte stores would misalign)
+#pragma unroll
+		for (int q = 0; q < 4; q++) {
+			int idx = q * 64 + lane;
+			float *d = tb + (idx >> 3) * ROW + (idx & 7) * 4;
+			*reinterpret_cast<float2 *>(d) = make_float2(pre[q].x, pre[q].y);
+			*reinterpret_cast<float2 *>(d + 2) = make_float2(pre[q].z, pre[q].w);
+		}
+		if (tl + 1 < n_tiles) {
+#pragma unroll
+			for (int q = 0; q < 4; q++) {
+				pre[q] = *reinterpret_cast<const float4 *>(ld_base[q] + (size_t)(tl + 1) * KF * 2);
+			}
+		}
+		__syncthreads();
+
+		float *mine = tb + sl * ROW + ear;
+		const int i0 = (int)(tl * KF);
+#pragma unroll 4
+		for (int k = 0; k < KF; k++) {
+			float x = mine[2 * k];
+			float y;
+			if constexpr (MODE == GAS_MODE_MIX_CHANNEL) {
+				const float fi = (float)(i0 + k);
+				const float t = f_pow2 ? fi * invF : fi / Ff; // (float)frame_idx / p_frame_count (:591)
+				const float vol = vf * t + (1 - t) * vs; // :592
+				x = vol * x; // :593
+			}
+			if constexpr (MODE == GAS_MODE_COPY) {
+				y = x;
+			} else {
+				// [ENGINE] process_one(_interp)
+				const float yf = x * co.b0 + hb1 * co.b1 + hb2 * co.b2 + ha1 * co.a1 + ha2 * co.a2;
+				if (all_filt) {
+					y = yf;
+					ha2 = ha1;
+					hb2 = hb1;
+					hb1 = x;
+					ha1 = yf;
+				} else {
+					// bypass branch (:530-535, :599-605) leaves the processor untouched
+					y = filt ? yf : x;
+					ha2 = filt ? ha1 : ha2;
+					hb2 = filt ? hb1 : hb2;
+					hb1 = filt ? x : hb1;
+					ha1 = filt ? yf : ha1;
+				}
+				if constexpr (MODE != GAS_MODE_FX_HIGHSHELF) {
+					co.b0 += inc.b0;
+					co.b1 += inc.b1;
+					co.b2 += inc.b2;
+					co.a1 += inc.a1;
+					co.a2 += inc.a2;
+				}
+			}
+			y = valid ? y : 0.0f;
+			const float a = fabsf(y);
+			peak = a > peak ? a : peak; // :436-443
+			mine[2 * k] = y;
+		}
+		__syncthreads();
+
+		// role switch: lane (h, j) sums column j = frame*2+ear over sources 16h .. 16h+15, in order
+		{
+			const int h = lane >> 5, j = lane & 31;
+			const float *col = tb + (16 * h) * ROW + j;
+			float s = 0.0f;
+#pragma unroll
+			for (int k = 0; k < 16; k++) {
+				s += col[k * ROW];
+			}
+			const float s_hi = __shfl_down(s, 32);
+			if (lane < 32) {
+				my_partial[(size_t)tl * (KF * 2) + j] = s + s_hi;
+			}
+		}
+		// the next iteration writes the other buffer; this one is rewritten two tiles later,
+		// after the __syncthreads() that follows that write.
+	}
+
+	if (valid) {
+		if constexpr (MODE != GAS_MODE_COPY) {
+			if (filt) {
+				bq[BQ_B0 * bs + stream] = co.b0;
+				bq[BQ_B1 * bs + stream] = co.b1;
+				bq[BQ_B2 * bs + stream] = co.b2;
+				bq[BQ_A1 * bs + stream] = co.a1;
+				bq[BQ_A2 * bs + stream] = co.a2;
+				bq[BQ_HA1 * bs + stream] = ha1;
+				bq[BQ_HA2 * bs + stream] = ha2;
+				bq[BQ_HB1 * bs + stream] = hb1;
+				bq[BQ_HB2 * bs + stream] = hb2;
+			}
+		}
+		if constexpr (MODE == GAS_MODE_MIX_CHANNEL || MODE == GAS_MODE_PROCESS_FRAMES) {
+			bq[BQ_PREV * bs + stream] = vf; // set_prev_mix_volume (:551, :608)
+		}
+		// per-source peak over all its channel pairs (:419-444): max is order-independent
+		atomicMax(reinterpret_cast<unsigned int *>(g.peaks) + (size_t)row * 2 + ear, __float_as_uint(peak));
+	}
+}
+
+} // namespace
+
+uint32_t gas_biquad_partials(uint32_t n) {
+	return (n + SRC_PER_WG - 1) / SRC_PER_WG;
+}
+
+hipError_t gas_launch_biquad_mix(hipStream_t stream, int mode, const gas_group_args &g, const gas_dev_state &st, uint32_t frames, uint32_t channel_begin, uint32_t channel_count, float mix_rate, float *partials, uint32_t p_offset, uint32_t p_stride) {
+	if (g.n == 0) {
+		return hipSuccess;
+	}
+	dim3 grid(gas_biquad_partials(g.n), channel_count);
+	dim3 block(64);
+	switch (mode) {
+		case GAS_MODE_MIX_CHANNEL:
+			hipLaunchKernelGGL(k_biquad_mix<GAS_MODE_MIX_CHANNEL>, grid, block, 0, stream, g, st, frames, channel_begin, mix_rate, partials, p_offset, p_stride);
+			break;
+		case GAS_MODE_PROCESS_FRAMES:
+			hipLaunchKernelGGL(k_biquad_mix<GAS_MODE_PROCESS_FRAMES>, grid, block, 0, stream, g, st, frames, channel_begin, mix_rate, partials, p_offset, p_stride);
+			break;
+		case GAS_MODE_FX_HIGHSHELF:
+			hipLaunchKernelGGL(k_biquad_mix<GAS_MODE_FX_HIGHSHELF>, grid, block, 0, stream, g, st, frames, channel_begin, mix_rate, partials, p_offset, p_stride);
+			break;
+		case GAS_MODE_COPY:
+			hipLaunchKernelGGL(k_biquad_mix<GAS_MODE_COPY>, grid, block, 0, stream, g, st, frames, channel_begin, mix_rate, partials, p_offset, p_stride);
+			break;
+		default:
+			return hipErrorInvalidValue;
+	}
+	return hipGetLastError();
+}

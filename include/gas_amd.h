@@ -1,0 +1,169 @@
+/*
+ * gas_amd.h -- C ABI of the MI355X-native many-source spatializer.
+ *
+ * This is the drop-in boundary for ONE path of BuzzLord/godot-audio-spatializer:
+ * the per-audio-callback work of AudioSpatializerInstance::_mix_from_playback_list
+ * (audio_spatializer.cpp:326-471) and the plugin DSP it dispatches to
+ * (audio_spatializer_3d.cpp:491-609, audio_spatializer_effect.cpp:33-77), batched
+ * over every active source in one launch group.  Plain pointers and sizes only;
+ * no exceptions cross it and nothing aborts: every entry returns 0 or a negative
+ * gas_status, mirroring the reference's ERR_FAIL_* "log and return" style
+ * (SURVEY.md section 5).  All file:line citations are in the reference tree.
+ *
+ * Threading contract (same split as audio_spatializer.h:135-138):
+ *   - gas_params_publish*  : physics thread, may run concurrently with the audio thread.
+ *   - gas_process_block, gas_process_frames_1, gas_mix_channel_1 : audio thread only,
+ *     one caller at a time, never re-entrant per context.
+ *   - everything else      : main thread, not concurrently with the audio thread.
+ */
+#ifndef GAS_AMD_H
+#define GAS_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GAS_ABI_VERSION 1
+
+/* audio_spatializer.h:47-52 */
+#define GAS_MAX_CHANNELS_PER_BUS 4
+#define GAS_LOOKAHEAD_BUFFER_SIZE 64
+#define GAS_MAX_BUSES_PER_PLAYBACK 6
+
+/* NEW (no reference counterpart): sizes of the HRTF / early-reflection effects. */
+#define GAS_HRTF_TAPS 256
+#define GAS_ER_TAPS 8
+#define GAS_MAX_EFFECTS 4
+
+typedef struct gas_ctx gas_ctx;
+
+/* [ENGINE] AudioFrame: two interleaved f32 (left, right), 8 bytes. */
+typedef struct gas_audio_frame {
+	float left, right;
+} gas_audio_frame;
+
+typedef enum gas_status {
+	GAS_OK = 0,
+	GAS_ERR_INVALID_ARGUMENT = -1,
+	GAS_ERR_OUT_OF_SLOTS = -2,
+	GAS_ERR_BAD_SLOT = -3,
+	GAS_ERR_FRAME_COUNT = -4, /* audio_spatializer.cpp:522 "Unexpected frame count" */
+	GAS_ERR_NO_HRTF = -5,
+	GAS_ERR_UNSUPPORTED_CHAIN = -6,
+	GAS_ERR_DEVICE = -7, /* a HIP call failed; gas_last_device_error() has the text */
+	GAS_ERR_NO_DEVICE = -8,
+	GAS_ERR_OUT_OF_MEMORY = -9,
+	GAS_ERR_KIND_MISMATCH = -10,
+	GAS_ERR_BAD_CHANNEL = -11, /* audio_spatializer.cpp:521 "Unexpected channel" */
+	GAS_ERR_NO_PARAMS = -12, /* audio_spatializer.cpp:330 parameters.is_null() */
+} gas_status;
+
+/* Which AudioSpatializerInstance flavour a source slot belongs to. */
+typedef enum gas_source_kind {
+	GAS_KIND_3D_MIX = 0, /* AudioSpatializer3D, mix_channel_mode=true : _mix_channel per channel pair (audio_spatializer_3d.cpp:554-609) */
+	GAS_KIND_3D_PROCESS = 1, /* AudioSpatializer3D, mix_channel_mode=false: _process_frames (audio_spatializer_3d.cpp:491-552) */
+	GAS_KIND_EFFECT = 2, /* AudioSpatializerEffect / AudioSpatializerHRTF: effect chain (audio_spatializer_effect.cpp:33-77) */
+} gas_source_kind;
+
+typedef enum gas_effect_kind {
+	GAS_FX_HIGHSHELF = 1, /* [ENGINE] AudioEffectHighShelfFilter, FILTER_6DB (gd_spatializer.gd:14-19) */
+	GAS_FX_EARLY_REFLECTIONS = 2, /* NEW: 8 stereo delay taps from a per-source ring */
+	GAS_FX_HRTF = 3, /* NEW: mono downmix -> gain ramp -> 256-tap HRIR pair, overlap-save FFT */
+} gas_effect_kind;
+
+typedef enum gas_mem {
+	GAS_MEM_HOST = 0, /* host pointers; the call copies in/out and returns when the result is in *out */
+	GAS_MEM_DEVICE = 1, /* device pointers on the context's GPU; the call only enqueues on the context stream */
+} gas_mem;
+
+/* Mirrors module initialisation (register_types.cpp:40) + the AudioServer facts the
+ * reference reads at run time (mix rate audio_spatializer_3d.cpp:506, channel count
+ * audio_spatializer.cpp:176, the fixed 512-frame mix step). */
+typedef struct gas_config {
+	uint32_t struct_size; /* sizeof(gas_config) */
+	int32_t device; /* HIP device ordinal */
+	uint32_t max_sources; /* slots of device-resident SpatializerPlaybackData */
+	uint32_t frames; /* F: frames per callback, fixed for the context (audio_spatializer.cpp:522); multiple of 128, <= 512 */
+	uint32_t channel_count; /* C: AudioServer channel pairs, 1..4 (audio_spatializer.cpp:172-179) */
+	float mix_rate; /* AudioServer::get_mix_rate(), e.g. 48000 */
+	uint32_t er_ring_frames; /* early-reflection ring length per source (power of two, 0 = effect unavailable) */
+	uint32_t flags; /* reserved, 0 */
+} gas_config;
+
+/* SpatializerParameters (spatializer_parameters.h:39-67) + SpatializerParameters3D
+ * (audio_spatializer_3d.h:61-83) as one 128-byte POD, plus the per-block effect
+ * parameters a _process_effects hook would push (audio_spatializer_effect.cpp:90-92,
+ * gd_spatializer_instance.gd:125-127).  bus_volumes stay on the host: they only feed
+ * AudioServer via get_bus_map (audio_spatializer.cpp:274-324). */
+typedef struct gas_params {
+	float mix_volumes[GAS_MAX_CHANNELS_PER_BUS][2]; /* must describe 4 channel pairs, spatializer_parameters.cpp:45 */
+	float pitch_scale; /* consumed by the host-side sampler only (audio_spatializer.cpp:375) */
+	float linear_attenuation; /* high-shelf gain, audio_spatializer_3d.h:67 */
+	float attenuation_filter_cutoff_hz; /* audio_spatializer_3d.h:68, default 5000 */
+	uint32_t update_parameters; /* spatializer_parameters.h:50, host-side only */
+	float hrtf_gain; /* NEW: linear gain ramped across the block before the HRIR */
+	uint32_t hrtf_dir; /* NEW: HRIR direction index */
+	float fx_shelf_gain; /* GAS_FX_HIGHSHELF gain (linear) */
+	float fx_shelf_cutoff_hz; /* GAS_FX_HIGHSHELF cutoff */
+	float er_gain[GAS_ER_TAPS]; /* NEW */
+	uint32_t er_delay[GAS_ER_TAPS]; /* NEW: 1 .. er_ring_frames - frames */
+} gas_params;
+
+/* Per-kernel device timing collected with HIP events on the context stream. */
+typedef struct gas_profile {
+	uint64_t launches; /* timed launches of the dominant kernel since the last reset */
+	double kernel_ms; /* sum of their durations */
+	uint64_t bytes_per_launch; /* algorithmic bytes of the last launch (SURVEY.md 8d formula) */
+	char kernel_name[64];
+} gas_profile;
+
+/* ---- context ---------------------------------------------------------- */
+int gas_abi_version(void);
+int gas_ctx_create(const gas_config *cfg, gas_ctx **out_ctx);
+void gas_ctx_destroy(gas_ctx *ctx);
+/* Run on an existing HIP stream (hipStream_t) instead of the context's own. */
+int gas_ctx_set_stream(gas_ctx *ctx, void *hip_stream);
+int gas_ctx_synchronize(gas_ctx *ctx);
+const char *gas_strerror(int status);
+const char *gas_last_device_error(gas_ctx *ctx);
+
+/* ---- per-playback state: _instantiate_playback_data (audio_spatializer.cpp:69),
+ * deferred delete (audio_spatializer.cpp:538-547) ------------------------ */
+int gas_source_alloc(gas_ctx *ctx, int kind, const int32_t *effects, uint32_t n_effects, uint32_t *out_slot);
+int gas_source_free(gas_ctx *ctx, uint32_t slot); /* takes effect at the next block boundary */
+int gas_source_reset(gas_ctx *ctx, uint32_t slot); /* zero the slot's DSP state (a restarted playback) */
+
+/* ---- set_spatializer_parameters (audio_spatializer.cpp:558-564): latest wins,
+ * snapshotted once at the start of the next gas_process_block (:328) ------ */
+int gas_params_publish(gas_ctx *ctx, uint32_t slot, const gas_params *params);
+int gas_params_publish_batch(gas_ctx *ctx, const uint32_t *slots, const gas_params *params, uint32_t n, int params_mem);
+
+/* ---- NEW AudioSpatializerHRTF resource: hrir is [dirs][2 ears][taps] f32, taps <= 256 */
+int gas_hrtf_load(gas_ctx *ctx, const float *hrir, uint32_t dirs, uint32_t taps);
+
+/* ---- the hot path: body of _mix_from_playback_list (audio_spatializer.cpp:353-470)
+ * for n sources at once.  src is [n][frames] AudioFrames, row i already holds the
+ * 64-frame-delayed window of source slots[i] (audio_spatializer.cpp:367-378);
+ * out is [C][frames] (C = channel_count for GAS_KIND_3D_MIX sources, else row 0 only
+ * is non-zero) and is fully overwritten (zeros when n == 0, :335-343); peaks is
+ * [n][2] = per-source max |L|, max |R| over its mixed output (:436-443,:453-460),
+ * feeding the host's silence gate (:464-469).  slots == NULL reuses the previous
+ * call's slot list (n must match).  On error the status is returned and, for host
+ * memory, *out is zero-filled. */
+int gas_process_block(gas_ctx *ctx, const gas_audio_frame *src, const uint32_t *slots, uint32_t n, uint32_t frames, gas_audio_frame *out, float *peaks, int mem);
+
+/* ---- compatibility / parity path: the exact _process_frames and _mix_channel
+ * signatures for one source (audio_spatializer.h:146,148), host pointers, synchronous. */
+int gas_process_frames_1(gas_ctx *ctx, uint32_t slot, gas_audio_frame *out, const gas_audio_frame *src, int frame_count);
+int gas_mix_channel_1(gas_ctx *ctx, uint32_t slot, int channel, gas_audio_frame *out, const gas_audio_frame *src, int frame_count);
+
+/* ---- measurement ------------------------------------------------------- */
+int gas_profile_enable(gas_ctx *ctx, int on);
+int gas_profile_read(gas_ctx *ctx, gas_profile *out, int reset);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GAS_AMD_H */

@@ -1,0 +1,729 @@
+/*
+ * gas_oracle.c -- CPU restatement of the godot-audio-spatializer hot path.
+ * TEST INFRASTRUCTURE ONLY; PARITY UNPINNED (see gas_oracle.h header).
+ *
+ * Plain C99, IEEE f32 op-for-op where the reference computes in f32; built with
+ * -O2 -ffp-contract=off (no fast-math, no FMA contraction) by oracle/Makefile.
+ * Citations are file:line in /root/reference/.  [ENGINE] marks arithmetic that
+ * lives in the un-vendored Godot engine and is restated from SURVEY.md Appendix B.
+ */
+#include "gas_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ------------------------------------------------------------------ */
+/* [ENGINE] Math::db_to_linear / linear_to_db (Appendix B)             */
+/* ------------------------------------------------------------------ */
+float gaso_db_to_linear(float db) {
+	return expf(db * 0.11512925464970228420089957273422f);
+}
+
+float gaso_linear_to_db(float lin) {
+	return logf(lin) * 8.6858896380650365530225783783321f;
+}
+
+/* ------------------------------------------------------------------ */
+/* [ENGINE] AudioFilterSW::prepare_coefficients, HIGHSHELF branch       */
+/* (call sites audio_spatializer_3d.cpp:504-510, 569-575).              */
+/* f64 arithmetic, members stored f32, then normalised by a0 with the   */
+/* feedback terms negated (Appendix B).                                 */
+/* ------------------------------------------------------------------ */
+void gaso_highshelf_coeffs(double sampling_rate, double cutoff, double resonance, double gain, int stages, gaso_coeffs *out) {
+	int sr_limit = (int)(sampling_rate / 2) + 512;
+	double final_cutoff = (cutoff > sr_limit) ? sr_limit : cutoff;
+	if (final_cutoff < 1) {
+		final_cutoff = 1;
+	}
+	double omega = 6.2831853071795864769252867666 * final_cutoff / sampling_rate;
+	double sin_v = sin(omega);
+	double cos_v = cos(omega);
+
+	double Q = resonance;
+	if (Q <= 0.0) {
+		Q = 0.0001;
+	}
+	double tmpgain = gain;
+	if (tmpgain < 0.001) {
+		tmpgain = 0.001;
+	}
+	if (stages > 1) {
+		Q = (Q > 1.0 ? pow(Q, 1.0 / stages) : Q);
+		tmpgain = pow(tmpgain, 1.0 / (stages + 1));
+	}
+
+	double tmpq = sqrt(Q);
+	if (tmpq <= 0) {
+		tmpq = 0.001;
+	}
+	double beta = sqrt(tmpgain) / tmpq;
+
+	double a0 = (tmpgain + 1.0) - (tmpgain - 1.0) * cos_v + beta * sin_v;
+	out->b0 = (float)(tmpgain * ((tmpgain + 1.0) + (tmpgain - 1.0) * cos_v + beta * sin_v));
+	out->b1 = (float)(-2.0 * tmpgain * ((tmpgain - 1.0) + (tmpgain + 1.0) * cos_v));
+	out->b2 = (float)(tmpgain * ((tmpgain + 1.0) + (tmpgain - 1.0) * cos_v - beta * sin_v));
+	out->a1 = (float)(2.0 * ((tmpgain - 1.0) - (tmpgain + 1.0) * cos_v));
+	out->a2 = (float)((tmpgain + 1.0) - (tmpgain - 1.0) * cos_v - beta * sin_v);
+
+	out->b0 = (float)(out->b0 / a0);
+	out->b1 = (float)(out->b1 / a0);
+	out->b2 = (float)(out->b2 / a0);
+	out->a1 = (float)(out->a1 / (0.0 - a0));
+	out->a2 = (float)(out->a2 / (0.0 - a0));
+}
+
+/* [ENGINE] AudioFilterSW::Processor::update_coeffs(len) (Appendix B). */
+void gaso_processor_update_coeffs(gaso_processor *p, const gaso_coeffs *target, int interp_len) {
+	if (interp_len) {
+		gaso_coeffs old = p->coeffs;
+		p->incr.a1 = (target->a1 - old.a1) / interp_len;
+		p->incr.a2 = (target->a2 - old.a2) / interp_len;
+		p->incr.b0 = (target->b0 - old.b0) / interp_len;
+		p->incr.b1 = (target->b1 - old.b1) / interp_len;
+		p->incr.b2 = (target->b2 - old.b2) / interp_len;
+		p->coeffs = old;
+	} else {
+		p->coeffs = *target;
+	}
+}
+
+/* [ENGINE] Processor::process_one (Appendix B). */
+float gaso_processor_process_one(gaso_processor *p, float x) {
+	float pre = x;
+	float y = (x * p->coeffs.b0 + p->hb1 * p->coeffs.b1 + p->hb2 * p->coeffs.b2 + p->ha1 * p->coeffs.a1 + p->ha2 * p->coeffs.a2);
+	p->ha2 = p->ha1;
+	p->hb2 = p->hb1;
+	p->hb1 = pre;
+	p->ha1 = y;
+	return y;
+}
+
+/* [ENGINE] Processor::process_one_interp (Appendix B): same, then coeffs += incr. */
+float gaso_processor_process_one_interp(gaso_processor *p, float x) {
+	float y = gaso_processor_process_one(p, x);
+	p->coeffs.b0 += p->incr.b0;
+	p->coeffs.b1 += p->incr.b1;
+	p->coeffs.b2 += p->incr.b2;
+	p->coeffs.a1 += p->incr.a1;
+	p->coeffs.a2 += p->incr.a2;
+	return y;
+}
+
+static void processor_set_filter(gaso_processor *p, int clear_history) {
+	if (clear_history) {
+		p->ha1 = p->ha2 = p->hb1 = p->hb2 = 0;
+	}
+}
+
+/* audio_spatializer_3d.cpp:873-885 */
+static void pd3d_get_prev(const gaso_pdata3d *pd, int channel, float out[2]) {
+	if (pd->prev_count <= channel) {
+		out[0] = 0.0f;
+		out[1] = 0.0f;
+		return;
+	}
+	out[0] = pd->prev_mix_volumes[channel][0];
+	out[1] = pd->prev_mix_volumes[channel][1];
+}
+
+static void pd3d_set_prev(gaso_pdata3d *pd, int channel, const float v[2]) {
+	if (pd->prev_count <= channel) {
+		/* Vector::resize value-initialises the new Vector2 entries to (0,0) [ENGINE]. */
+		for (int c = pd->prev_count; c <= channel; c++) {
+			pd->prev_mix_volumes[c][0] = 0.0f;
+			pd->prev_mix_volumes[c][1] = 0.0f;
+		}
+		pd->prev_count = channel + 1;
+	}
+	pd->prev_mix_volumes[channel][0] = v[0];
+	pd->prev_mix_volumes[channel][1] = v[1];
+}
+
+/* ------------------------------------------------------------------ */
+/* AudioSpatializerInstance3D::process_frames                           */
+/* audio_spatializer_3d.cpp:491-552                                     */
+/* ------------------------------------------------------------------ */
+void gaso_process_frames_3d(const gaso_params *params, gaso_pdata3d *pd, gaso_frame *out, const gaso_frame *src, int n, float mix_rate) {
+	float prev_vol[2];
+	pd3d_get_prev(pd, 0, prev_vol); /* :500 */
+
+	float highshelf_gain = params->linear_attenuation; /* :502 */
+	if (highshelf_gain >= 0.001) { /* :503 (float promoted to double against 0.001) */
+		gaso_coeffs target;
+		gaso_highshelf_coeffs(mix_rate, params->attenuation_filter_cutoff_hz, 1, highshelf_gain, 1, &target); /* :504-510 */
+		gaso_processor *pl = &pd->filter_processors[0]; /* :512 */
+		gaso_processor *pr = &pd->filter_processors[1]; /* :513 */
+		int is_just_started = prev_vol[0] == 0 && prev_vol[1] == 0; /* :518 */
+		processor_set_filter(pl, is_just_started);
+		gaso_processor_update_coeffs(pl, &target, n);
+		processor_set_filter(pr, is_just_started);
+		gaso_processor_update_coeffs(pr, &target, n);
+		for (int i = 0; i < n; i++) { /* :524-529 */
+			gaso_frame mixed = src[i];
+			mixed.l = gaso_processor_process_one_interp(pl, mixed.l);
+			mixed.r = gaso_processor_process_one_interp(pr, mixed.r);
+			out[i] = mixed;
+		}
+	} else {
+		for (int i = 0; i < n; i++) { /* :531-534 */
+			out[i] = src[i];
+		}
+	}
+
+	float max_volume = 0.0f; /* :537-548 */
+	int max_index = 0;
+	for (int i = 0; i < GASO_MAX_CHANNELS_PER_BUS; i++) {
+		if (params->mix_volumes[i][0] > max_volume) {
+			max_volume = params->mix_volumes[i][0];
+			max_index = i;
+		}
+		if (params->mix_volumes[i][1] > max_volume) {
+			max_volume = params->mix_volumes[i][1];
+			max_index = i;
+		}
+	}
+	pd3d_set_prev(pd, 0, params->mix_volumes[max_index]); /* :551 */
+}
+
+/* ------------------------------------------------------------------ */
+/* AudioSpatializerInstance3D::mix_channel                              */
+/* audio_spatializer_3d.cpp:554-609                                     */
+/* ------------------------------------------------------------------ */
+void gaso_mix_channel_3d(const gaso_params *params, gaso_pdata3d *pd, int channel, gaso_frame *out, const gaso_frame *src, int n, float mix_rate) {
+	float vs[2];
+	pd3d_get_prev(pd, channel, vs); /* :564 */
+	const float vf[2] = { params->mix_volumes[channel][0], params->mix_volumes[channel][1] }; /* :565 */
+
+	float highshelf_gain = params->linear_attenuation;
+	if (highshelf_gain >= 0.001) { /* :568 */
+		gaso_coeffs target;
+		gaso_highshelf_coeffs(mix_rate, params->attenuation_filter_cutoff_hz, 1, highshelf_gain, 1, &target);
+		gaso_processor *pl = &pd->filter_processors[channel * 2]; /* :887-894 */
+		gaso_processor *pr = &pd->filter_processors[channel * 2 + 1];
+		int is_just_started = vs[0] == 0 && vs[1] == 0; /* :583 */
+		processor_set_filter(pl, is_just_started);
+		gaso_processor_update_coeffs(pl, &target, n);
+		processor_set_filter(pr, is_just_started);
+		gaso_processor_update_coeffs(pr, &target, n);
+		for (int i = 0; i < n; i++) { /* :589-597 */
+			float t = (float)i / n;
+			/* AudioFrame vol = p_vol_final * t + (1 - t) * p_vol_start; */
+			float one_minus = 1 - t;
+			float vol_l = vf[0] * t + one_minus * vs[0];
+			float vol_r = vf[1] * t + one_minus * vs[1];
+			float ml = vol_l * src[i].l;
+			float mr = vol_r * src[i].r;
+			ml = gaso_processor_process_one_interp(pl, ml);
+			mr = gaso_processor_process_one_interp(pr, mr);
+			out[i].l = ml;
+			out[i].r = mr;
+		}
+	} else {
+		for (int i = 0; i < n; i++) { /* :600-604 */
+			float t = (float)i / n;
+			float one_minus = 1 - t;
+			out[i].l = (vf[0] * t + one_minus * vs[0]) * src[i].l;
+			out[i].r = (vf[1] * t + one_minus * vs[1]) * src[i].r;
+		}
+	}
+	pd3d_set_prev(pd, channel, vf); /* :608 */
+}
+
+/* ------------------------------------------------------------------ */
+/* Effects                                                              */
+/* ------------------------------------------------------------------ */
+
+/* [ENGINE] AudioEffectFilterInstance::process for AudioEffectHighShelfFilter at
+ * FILTER_6DB: coefficients snapped every call (update_coeffs() with no
+ * interpolation), process_one over all left samples then all right samples
+ * (Appendix B; example gd_spatializer.gd:14-19). */
+static void fx_highshelf(const gaso_params *params, gaso_fx_state *st, const gaso_frame *src, gaso_frame *dst, int n, float mix_rate) {
+	gaso_coeffs target;
+	gaso_highshelf_coeffs(mix_rate, params->fx_shelf_cutoff_hz, 1.0, params->fx_shelf_gain, 1, &target);
+	gaso_processor_update_coeffs(&st->shelf[0], &target, 0);
+	gaso_processor_update_coeffs(&st->shelf[1], &target, 0);
+	for (int i = 0; i < n; i++) {
+		dst[i].l = gaso_processor_process_one(&st->shelf[0], src[i].l);
+	}
+	for (int i = 0; i < n; i++) {
+		dst[i].r = gaso_processor_process_one(&st->shelf[1], src[i].r);
+	}
+}
+
+/* NEW (no reference code): 8-tap early reflections on the stereo frames.
+ * y[i] = x[i] + sum_k er_gain[k] * x[i - er_delay[k]], history kept in a
+ * per-playback ring of ring_frames frames (zeros before the stream started).
+ * Taps accumulate in tap order in f32. 1 <= er_delay[k] <= ring_frames - n. */
+static void fx_early_reflections(const gaso_params *params, gaso_fx_state *st, const gaso_frame *src, gaso_frame *dst, int n) {
+	const uint32_t R = st->ring_frames;
+	uint32_t pos = st->ring_pos;
+	/* dst may alias nothing of the ring; src may equal dst is NOT allowed by the chain. */
+	for (int i = 0; i < n; i++) {
+		st->ring[(pos + (uint32_t)i) % R] = src[i];
+	}
+	for (int i = 0; i < n; i++) {
+		float yl = src[i].l;
+		float yr = src[i].r;
+		for (int k = 0; k < GASO_ER_TAPS; k++) {
+			uint32_t d = params->er_delay[k];
+			gaso_frame x = st->ring[(pos + (uint32_t)i + R - d) % R];
+			yl = yl + params->er_gain[k] * x.l;
+			yr = yr + params->er_gain[k] * x.r;
+		}
+		dst[i].l = yl;
+		dst[i].r = yr;
+	}
+	st->ring_pos = (pos + (uint32_t)n) % R;
+}
+
+/* NEW (no reference code): per-source HRTF.  mono = (l + r) * 0.5; gain ramps
+ * like the reference's volume lerp (audio_spatializer_3d.cpp:591-592, t = i/n);
+ * x = mono * gain; stereo out = direct-form 256-tap FIR with the HRIR pair of
+ * direction hrtf_dir over hist ++ x, accumulated in f64 (the float64 oracle
+ * SURVEY.md section 8c asks for), rounded to f32.  The direction switches at the
+ * block boundary without cross-fade. */
+static void hrtf_make_x(const gaso_params *params, gaso_fx_state *st, const gaso_frame *src, float *xx /* [T-1+n] */, int n) {
+	const int H = GASO_HRTF_TAPS - 1;
+	memcpy(xx, st->hist, sizeof(float) * H);
+	float g0 = st->prev_gain;
+	float g1 = params->hrtf_gain;
+	for (int i = 0; i < n; i++) {
+		float t = (float)i / n;
+		float g = g1 * t + (1 - t) * g0;
+		float mono = (src[i].l + src[i].r) * 0.5f;
+		xx[H + i] = mono * g;
+	}
+}
+
+static void hrtf_commit(const gaso_params *params, gaso_fx_state *st, const float *xx, int n) {
+	const int H = GASO_HRTF_TAPS - 1;
+	memmove(st->hist, xx + n, sizeof(float) * H); /* last T-1 samples of hist ++ x */
+	st->prev_gain = params->hrtf_gain;
+}
+
+static void fx_hrtf(const gaso_params *params, gaso_fx_state *st, const gaso_hrtf *hrtf, const gaso_frame *src, gaso_frame *dst, int n) {
+	const int T = GASO_HRTF_TAPS;
+	const int H = T - 1;
+	float *xx = (float *)malloc(sizeof(float) * (size_t)(H + n));
+	hrtf_make_x(params, st, src, xx, n);
+	uint32_t dir = params->hrtf_dir < hrtf->dirs ? params->hrtf_dir : 0;
+	const float *hl = hrtf->hrir + (size_t)dir * 2 * T;
+	const float *hr = hl + T;
+	for (int i = 0; i < n; i++) {
+		double al = 0.0, ar = 0.0;
+		const float *xp = xx + H + i;
+		for (int k = 0; k < T; k++) {
+			double x = xp[-k];
+			al += (double)hl[k] * x;
+			ar += (double)hr[k] * x;
+		}
+		dst[i].l = (float)al;
+		dst[i].r = (float)ar;
+	}
+	hrtf_commit(params, st, xx, n);
+	free(xx);
+}
+
+void gaso_fx_process(int kind, const gaso_params *params, gaso_fx_state *st, const gaso_hrtf *hrtf, const gaso_frame *src, gaso_frame *dst, int n, float mix_rate) {
+	switch (kind) {
+		case GASO_FX_HIGHSHELF:
+			fx_highshelf(params, st, src, dst, n, mix_rate);
+			break;
+		case GASO_FX_EARLY_REFLECTIONS:
+			fx_early_reflections(params, st, src, dst, n);
+			break;
+		case GASO_FX_HRTF:
+			if (hrtf->impl == 1) {
+				gaso_hrtf_ols_radix2(params, st, hrtf, src, dst, n);
+			} else {
+				fx_hrtf(params, st, hrtf, src, dst, n);
+			}
+			break;
+		default:
+			for (int i = 0; i < n; i++) {
+				dst[i] = src[i];
+			}
+	}
+}
+
+/* ------------------------------------------------------------------ */
+/* AudioSpatializerInstanceEffect::process_frames                       */
+/* audio_spatializer_effect.cpp:33-77                                   */
+/* (_process_effects, :39/:90-92, is the caller's hook: its effect is   */
+/* already folded into *params.)                                        */
+/* ------------------------------------------------------------------ */
+uint32_t gaso_process_frames_effect(const gaso_params *params, gaso_pdata_effect *pd, const gaso_hrtf *hrtf, gaso_frame *out, const gaso_frame *src, int n, gaso_frame *temp, float mix_rate) {
+	uint32_t trace = 0;
+	int E = pd->n_effects;
+	if (E == 0) { /* :41-46 */
+		for (int i = 0; i < n; i++) {
+			out[i] = src[i];
+		}
+		return 0;
+	}
+	for (int j = 0; j < E; j++) { /* :52-76 */
+		int is_even = ((j + E) % 2 == 0);
+		const gaso_frame *s;
+		gaso_frame *d;
+		if (j == 0) {
+			s = src;
+		} else if (is_even) {
+			s = out;
+		} else {
+			s = temp;
+			trace |= 1u << (2 * j + 1);
+		}
+		if (is_even) {
+			d = temp;
+			trace |= 1u << (2 * j);
+		} else {
+			d = out;
+		}
+		gaso_fx_process(pd->kinds[j], params, &pd->fx[j], hrtf, s, d, n, mix_rate);
+	}
+	return trace;
+}
+
+/* ------------------------------------------------------------------ */
+/* AudioSpatializerInstance mixer, audio_spatializer.cpp:326-527        */
+/* ------------------------------------------------------------------ */
+
+/* Synthetic stand-in for [ENGINE] AudioStreamPlayback::mix: copies what is left
+ * of the stream, zero-fills the remainder, returns the number of real frames. */
+static int stream_mix(gaso_playback *pb, gaso_frame *dst, int n) {
+	int64_t left = pb->stream_frames - pb->stream_pos;
+	int m = (int)(left < n ? (left < 0 ? 0 : left) : n);
+	for (int i = 0; i < m; i++) {
+		dst[i] = pb->stream[pb->stream_pos + i];
+	}
+	for (int i = m; i < n; i++) {
+		dst[i].l = 0.0f;
+		dst[i].r = 0.0f;
+	}
+	pb->stream_pos += m;
+	return m;
+}
+
+/* audio_spatializer.cpp:367-408 */
+void gaso_fetch_source(gaso_playback *pb, gaso_frame *buf, int n) {
+	if (pb->has_frames) {
+		for (int i = 0; i < GASO_LOOKAHEAD; i++) { /* :371-373 */
+			buf[i] = pb->lookahead[i];
+		}
+		int mixed_frames = stream_mix(pb, &buf[GASO_LOOKAHEAD], n); /* :378 */
+		if (mixed_frames != n) { /* :380-398 */
+			float fadeout_base = 0.96;
+			float fadeout_coefficient = 1;
+			float buffer_size_float = (float)GASO_LOOKAHEAD;
+			float buffer_linear_fade_idx = 0.0;
+			int fade_limit = mixed_frames + GASO_LOOKAHEAD;
+			for (int idx = mixed_frames; idx < n; idx++) {
+				if (idx < fade_limit) {
+					fadeout_coefficient *= fadeout_base;
+					float f = fadeout_coefficient * (buffer_size_float - buffer_linear_fade_idx) / buffer_size_float;
+					buf[idx].l *= f;
+					buf[idx].r *= f;
+					buffer_linear_fade_idx += 1.0;
+				} else {
+					buf[idx].l *= 0.0f; /* NaN-preserving zeroing, :394 */
+					buf[idx].r *= 0.0f;
+				}
+			}
+			pb->has_frames = 0;
+		} else {
+			for (int i = 0; i < GASO_LOOKAHEAD; i++) { /* :401-403 */
+				pb->lookahead[i] = buf[n + i];
+			}
+		}
+	} else {
+		for (int i = 0; i < n + GASO_LOOKAHEAD; i++) { /* :407 */
+			buf[i].l = 0;
+			buf[i].r = 0;
+		}
+	}
+}
+
+static int kind_should_process_frames(int kind) {
+	return kind != GASO_KIND_3D_MIX; /* audio_spatializer_3d.h:145; audio_spatializer_effect.h:57 */
+}
+
+static int kind_should_mix_channels(int kind) {
+	return kind == GASO_KIND_3D_MIX; /* audio_spatializer_3d.h:146; audio_spatializer_effect.h:58 */
+}
+
+/* audio_spatializer.cpp:410-462 minus the += into mix_buffer. */
+void gaso_playback_contribution(gaso_instance *inst, const gaso_params *params, gaso_pdata3d *pd3d, gaso_pdata_effect *pdfx, const gaso_frame *buf, int n, gaso_frame *const contrib[GASO_MAX_CHANNELS_PER_BUS], float peak[2]) {
+	const gaso_frame *processed;
+	if (kind_should_process_frames(inst->kind)) { /* :411-414 */
+		if (inst->kind == GASO_KIND_3D_PROCESS) {
+			gaso_process_frames_3d(params, pd3d, inst->process_buffer, buf, n, inst->mix_rate);
+		} else {
+			gaso_process_frames_effect(params, pdfx, inst->hrtf, inst->process_buffer, buf, n, inst->fx_temp, inst->mix_rate);
+		}
+		processed = inst->process_buffer;
+	} else {
+		processed = buf;
+	}
+	peak[0] = 0;
+	peak[1] = 0;
+	if (kind_should_mix_channels(inst->kind)) { /* :421-445 */
+		for (int c = 0; c < inst->channel_count; c++) {
+			gaso_frame *o = inst->temp_buffer;
+			gaso_mix_channel_3d(params, pd3d, c, o, processed, n, inst->mix_rate);
+			for (int i = 0; i < n; i++) {
+				contrib[c][i] = o[i];
+				float l = fabsf(o[i].l);
+				if (l > peak[0]) {
+					peak[0] = l;
+				}
+				float r = fabsf(o[i].r);
+				if (r > peak[1]) {
+					peak[1] = r;
+				}
+			}
+		}
+	} else { /* :446-462 */
+		for (int i = 0; i < n; i++) {
+			contrib[0][i] = processed[i];
+			float l = fabsf(processed[i].l);
+			if (l > peak[0]) {
+				peak[0] = l;
+			}
+			float r = fabsf(processed[i].r);
+			if (r > peak[1]) {
+				peak[1] = r;
+			}
+		}
+	}
+}
+
+void gaso_mix_from_playback_list(gaso_instance *inst, const gaso_params *const *params, gaso_playback *const *playbacks, int n_playbacks, int n) {
+	for (int c = 0; c < inst->channel_count; c++) { /* :335-343 */
+		for (int i = 0; i < n; i++) {
+			inst->mix_buffer[c][i].l = 0.f;
+			inst->mix_buffer[c][i].r = 0.f;
+		}
+	}
+	inst->mix_buffer_size = n;
+	gaso_frame *contrib[GASO_MAX_CHANNELS_PER_BUS];
+	for (int c = 0; c < GASO_MAX_CHANNELS_PER_BUS; c++) {
+		contrib[c] = (gaso_frame *)malloc(sizeof(gaso_frame) * (size_t)n);
+	}
+	for (int p = 0; p < n_playbacks; p++) { /* :353 */
+		gaso_playback *pb = playbacks[p];
+		if (!pb->active) { /* :355-357 */
+			continue;
+		}
+		gaso_frame *buf = inst->playback_buffer;
+		gaso_fetch_source(pb, buf, n);
+		float peak[2];
+		gaso_playback_contribution(inst, params[p], &pb->pd3d, &pb->pdfx, buf, n, contrib, peak);
+		int channels = kind_should_mix_channels(inst->kind) ? inst->channel_count : 1;
+		for (int c = 0; c < channels; c++) { /* :433-434, :450-451 */
+			for (int i = 0; i < n; i++) {
+				inst->mix_buffer[c][i].l += contrib[c][i].l;
+				inst->mix_buffer[c][i].r += contrib[c][i].r;
+			}
+		}
+		pb->last_peak[0] = peak[0];
+		pb->last_peak[1] = peak[1];
+		if (!pb->has_frames) { /* :464-469 */
+			float m = peak[1] > peak[0] ? peak[1] : peak[0];
+			if (m <= gaso_db_to_linear(inst->disable_threshold_db)) {
+				pb->active = 0;
+			}
+		}
+	}
+	for (int c = 0; c < GASO_MAX_CHANNELS_PER_BUS; c++) {
+		free(contrib[c]);
+	}
+}
+
+/* audio_spatializer.cpp:494-508 */
+int gaso_check_channel_mixed(gaso_instance *inst, int channel) {
+	if (inst->channel_mixed[channel]) {
+		for (int c = 0; c < GASO_MAX_CHANNELS_PER_BUS; c++) {
+			inst->channel_mixed[c] = 0;
+		}
+		inst->channel_mixed[channel] = 1;
+		return 1;
+	}
+	inst->channel_mixed[channel] = 1;
+	return 0;
+}
+
+/* audio_spatializer.cpp:510-527; returns 0 ok, -1 on the ERR_FAIL paths (:521-522). */
+int gaso_get_mixed_frames(gaso_instance *inst, const gaso_params *const *params, gaso_playback *const *playbacks, int n_playbacks, int channel, gaso_frame *frames, int n) {
+	if (gaso_check_channel_mixed(inst, channel)) {
+		gaso_mix_from_playback_list(inst, params, playbacks, n_playbacks, n);
+	}
+	if (channel < 0 || channel >= inst->channel_count) {
+		return -1;
+	}
+	if (n != inst->mix_buffer_size) {
+		return -1;
+	}
+	for (int i = 0; i < n; i++) {
+		frames[i] = inst->mix_buffer[channel][i];
+	}
+	return 0;
+}
+
+/* audio_spatializer.cpp:295-319, one bus. */
+void gaso_bus_map(int should_mix_channels, int channel, const float bus_volume[4][2], const float mix_volumes[4][2], float out[4][2]) {
+	for (int c = 0; c < GASO_MAX_CHANNELS_PER_BUS; c++) {
+		if (should_mix_channels) {
+			float left = 0.0f, right = 0.0f;
+			if (c == channel) {
+				if (mix_volumes[c][0] > 0.0) {
+					left = bus_volume[c][0] / mix_volumes[c][0];
+				}
+				if (mix_volumes[c][1] > 0.0) {
+					right = bus_volume[c][1] / mix_volumes[c][1];
+				}
+			}
+			out[c][0] = left;
+			out[c][1] = right;
+		} else {
+			out[c][0] = mix_volumes[c][0];
+			out[c][1] = mix_volumes[c][1];
+		}
+	}
+}
+
+/* ------------------------------------------------------------------ */
+/* Batched convenience: what one callback computes for n_src sources    */
+/* that are all active with a full window already fetched.              */
+/* ------------------------------------------------------------------ */
+void gaso_batch_block(int kind, int channel_count, const gaso_params *params, gaso_batch_state *states, const gaso_hrtf *hrtf, const gaso_frame *src, int n_src, int n, float mix_rate, gaso_frame *mix, double *mix64, float *peaks) {
+	gaso_instance inst;
+	memset(&inst, 0, sizeof(inst));
+	inst.kind = kind;
+	inst.channel_count = kind_should_mix_channels(kind) ? channel_count : 1;
+	inst.mix_rate = mix_rate;
+	inst.hrtf = hrtf;
+	inst.process_buffer = (gaso_frame *)malloc(sizeof(gaso_frame) * (size_t)n);
+	inst.temp_buffer = (gaso_frame *)malloc(sizeof(gaso_frame) * (size_t)n);
+	inst.fx_temp = (gaso_frame *)malloc(sizeof(gaso_frame) * (size_t)n);
+	gaso_frame *contrib[GASO_MAX_CHANNELS_PER_BUS];
+	for (int c = 0; c < GASO_MAX_CHANNELS_PER_BUS; c++) {
+		contrib[c] = (gaso_frame *)malloc(sizeof(gaso_frame) * (size_t)n);
+	}
+	int C = inst.channel_count;
+	for (int c = 0; c < C; c++) {
+		for (int i = 0; i < n; i++) {
+			mix[(size_t)c * n + i].l = 0.f;
+			mix[(size_t)c * n + i].r = 0.f;
+			if (mix64) {
+				mix64[((size_t)c * n + i) * 2] = 0.0;
+				mix64[((size_t)c * n + i) * 2 + 1] = 0.0;
+			}
+		}
+	}
+	for (int s = 0; s < n_src; s++) {
+		float peak[2];
+		gaso_playback_contribution(&inst, &params[s], &states[s].pd3d, &states[s].pdfx, src + (size_t)s * n, n, contrib, peak);
+		for (int c = 0; c < C; c++) {
+			for (int i = 0; i < n; i++) {
+				mix[(size_t)c * n + i].l += contrib[c][i].l;
+				mix[(size_t)c * n + i].r += contrib[c][i].r;
+				if (mix64) {
+					mix64[((size_t)c * n + i) * 2] += (double)contrib[c][i].l;
+					mix64[((size_t)c * n + i) * 2 + 1] += (double)contrib[c][i].r;
+				}
+			}
+		}
+		if (peaks) {
+			peaks[2 * s] = peak[0];
+			peaks[2 * s + 1] = peak[1];
+		}
+	}
+	for (int c = 0; c < GASO_MAX_CHANNELS_PER_BUS; c++) {
+		free(contrib[c]);
+	}
+	free(inst.process_buffer);
+	free(inst.temp_buffer);
+	free(inst.fx_temp);
+}
+
+/* ------------------------------------------------------------------ */
+/* CPU baseline arithmetic for HRTF: overlap-save, plain radix-2 FFT.   */
+/* ------------------------------------------------------------------ */
+static void fft_radix2(float *re, float *im, int n, int inverse) {
+	for (int i = 1, j = 0; i < n; i++) {
+		int bit = n >> 1;
+		for (; j & bit; bit >>= 1) {
+			j ^= bit;
+		}
+		j ^= bit;
+		if (i < j) {
+			float t = re[i];
+			re[i] = re[j];
+			re[j] = t;
+			t = im[i];
+			im[i] = im[j];
+			im[j] = t;
+		}
+	}
+	for (int len = 2; len <= n; len <<= 1) {
+		double ang = 2.0 * 3.14159265358979323846 / len * (inverse ? 1.0 : -1.0);
+		int half = len >> 1;
+		for (int k = 0; k < half; k++) {
+			float wr = (float)cos(ang * k);
+			float wi = (float)sin(ang * k);
+			for (int i = k; i < n; i += len) {
+				int j = i + half;
+				float tr = re[j] * wr - im[j] * wi;
+				float ti = re[j] * wi + im[j] * wr;
+				re[j] = re[i] - tr;
+				im[j] = im[i] - ti;
+				re[i] += tr;
+				im[i] += ti;
+			}
+		}
+	}
+}
+
+void gaso_hrtf_ols_radix2(const gaso_params *params, gaso_fx_state *st, const gaso_hrtf *hrtf, const gaso_frame *src, gaso_frame *dst, int n) {
+	const int T = GASO_HRTF_TAPS;
+	const int H = T - 1;
+	int L = 1;
+	while (L < n + H) {
+		L <<= 1;
+	}
+	float *xx = (float *)malloc(sizeof(float) * (size_t)(H + n));
+	hrtf_make_x(params, st, src, xx, n);
+	uint32_t dir = params->hrtf_dir < hrtf->dirs ? params->hrtf_dir : 0;
+	const float *h[2] = { hrtf->hrir + (size_t)dir * 2 * T, hrtf->hrir + (size_t)dir * 2 * T + T };
+	float *buf = (float *)calloc((size_t)L * 6, sizeof(float));
+	float *xr = buf, *xi = buf + L, *hr = buf + 2 * L, *hi = buf + 3 * L, *yr = buf + 4 * L, *yi = buf + 5 * L;
+	/* window = last L samples ending at the block end, zero-extended on the left */
+	for (int i = 0; i < H + n; i++) {
+		xr[L - (H + n) + i] = xx[i];
+	}
+	fft_radix2(xr, xi, L, 0);
+	for (int ear = 0; ear < 2; ear++) {
+		memset(hr, 0, sizeof(float) * (size_t)L);
+		memset(hi, 0, sizeof(float) * (size_t)L);
+		memcpy(hr, h[ear], sizeof(float) * T);
+		fft_radix2(hr, hi, L, 0);
+		for (int k = 0; k < L; k++) {
+			yr[k] = xr[k] * hr[k] - xi[k] * hi[k];
+			yi[k] = xr[k] * hi[k] + xi[k] * hr[k];
+		}
+		fft_radix2(yr, yi, L, 1);
+		float scale = 1.0f / L;
+		for (int i = 0; i < n; i++) {
+			float v = yr[L - n + i] * scale;
+			if (ear == 0) {
+				dst[i].l = v;
+			} else {
+				dst[i].r = v;
+			}
+		}
+	}
+	hrtf_commit(params, st, xx, n);
+	free(buf);
+	free(xx);
+}

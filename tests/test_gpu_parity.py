@@ -1,0 +1,103 @@
+"""GPU parity: the HIP path through the C ABI vs the CPU oracle on identical seeded inputs.
+
+Tolerance: 1e-5 relative RMS per callback (BASELINE.json north_star), peaks to 1e-5 relative.
+PARITY UNPINNED at the engine boundary (oracle/gas_oracle.h).
+"""
+import numpy as np
+import pytest
+
+from helpers import TOL, rel_rms
+
+pytestmark = pytest.mark.gpu
+
+ORACLE_KIND = {0: 0, 1: 1, 2: 2}
+
+
+def run_pair(gas, ob, kind, chain, n, frames, blocks, channel_count=1, seed=0, dirs=64, redraw_every=2, ring=0, hrir=None, params_hook=None):
+    from godot_audio_spatializer_amd import synth
+
+    rng = np.random.default_rng(seed)
+    C = channel_count if kind == gas.capi.KIND_3D_MIX else 1
+    ctx = gas.SpatializerContext(max_sources=n + 8, frames=frames, channel_count=channel_count, er_ring_frames=ring)
+    if hrir is not None:
+        ctx.hrtf_load(hrir)
+    slots = ctx.source_alloc_many(n, kind, chain)
+    ora = ob.BatchOracle(kind, n, frames, channel_count=channel_count, chain=chain, hrir=hrir, er_ring_frames=max(ring, 1))
+    worst = 0.0
+    for b in range(blocks):
+        if b % redraw_every == 0:
+            p = synth.draw_params(rng, n, dirs=dirs, channel_count=channel_count, ring_frames=max(ring, 2 * frames), frames=frames)
+            if params_hook:
+                params_hook(b, p)
+            ctx.params_publish_batch(slots, p)
+        src = synth.draw_sources(rng, n, frames)
+        mix, peaks = ctx.process_block(src, slots)
+        rmix, rpeaks, rmix64 = ora.block(p.astype(ob.PARAMS_DTYPE), src, want64=True)
+        assert mix.shape == (channel_count, frames, 2)
+        for c in range(C):
+            e = rel_rms(mix[c], rmix64[c])
+            worst = max(worst, e)
+            assert e <= TOL, f"block {b} channel {c}: rel rms {e}"
+        for c in range(C, channel_count):
+            assert not mix[c].any()
+        np.testing.assert_allclose(peaks, rpeaks, rtol=2e-5, atol=1e-7)
+    ctx.close()
+    return worst
+
+
+@pytest.mark.parametrize("n", [1, 31, 256])
+def test_mix_channel_cfg2(gas, ob, n):
+    """cfg2: pan ramp + distance high-shelf (mix_channel), F=512, stereo."""
+    run_pair(gas, ob, gas.capi.KIND_3D_MIX, (), n, 512, 6)
+
+
+def test_mix_channel_four_pairs(gas, ob):
+    run_pair(gas, ob, gas.capi.KIND_3D_MIX, (), 96, 512, 5, channel_count=4)
+
+
+def test_mix_channel_bypass_branch(gas, ob):
+    """linear_attenuation < 0.001 takes the gain-only branch (audio_spatializer_3d.cpp:599-605) for some sources."""
+
+    def hook(b, p):
+        p["linear_attenuation"][::3] = 0.0005
+        if b >= 2:
+            p["linear_attenuation"][1::3] = 0.0
+
+    run_pair(gas, ob, gas.capi.KIND_3D_MIX, (), 100, 512, 6, params_hook=hook)
+
+
+def test_process_frames_mode(gas, ob):
+    run_pair(gas, ob, gas.capi.KIND_3D_PROCESS, (), 130, 512, 6)
+
+
+def test_process_frames_256(gas, ob):
+    run_pair(gas, ob, gas.capi.KIND_3D_PROCESS, (), 70, 256, 5)
+
+
+def test_effect_empty_chain(gas, ob):
+    run_pair(gas, ob, gas.capi.KIND_EFFECT, (), 40, 512, 2)
+
+
+def test_effect_highshelf(gas, ob):
+    run_pair(gas, ob, gas.capi.KIND_EFFECT, (gas.capi.FX_HIGHSHELF,), 77, 512, 5)
+
+
+@pytest.mark.parametrize("frames,n", [(512, 1), (512, 67), (256, 130), (512, 300)])
+def test_hrtf(gas, ob, frames, n):
+    """cfg3 shape at oracle-friendly size: per-source 256-tap HRTF, direction redrawn every 2 callbacks."""
+    from godot_audio_spatializer_amd import synth
+
+    hrir = synth.synthetic_hrir(np.random.default_rng(7), dirs=64)
+    run_pair(gas, ob, gas.capi.KIND_EFFECT, (gas.capi.FX_HRTF,), n, frames, 5, hrir=hrir)
+
+
+def test_er_hrtf_cfg5(gas, ob):
+    """cfg5 shape: 8-tap early reflections -> HRTF, F=256, ring 4096."""
+    from godot_audio_spatializer_amd import synth
+
+    hrir = synth.synthetic_hrir(np.random.default_rng(7), dirs=64)
+    run_pair(gas, ob, gas.capi.KIND_EFFECT, (gas.capi.FX_EARLY_REFLECTIONS, gas.capi.FX_HRTF), 90, 256, 20, hrir=hrir, ring=4096, redraw_every=3)
+
+
+def test_er_only(gas, ob):
+    run_pair(gas, ob, gas.capi.KIND_EFFECT, (gas.capi.FX_EARLY_REFLECTIONS,), 50, 256, 20, ring=4096, redraw_every=3)
