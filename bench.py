@@ -1,0 +1,283 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark: mixed AudioFrames/s of the batched spatializer hot path.
+
+One "step" = one audio callback: every active source's F-frame AudioFrame buffer (already resident
+in HBM) -> per-source spatialization -> N-source stereo mix, through the C ABI (gas_process_block).
+Default workload = BASELINE.json configs[3]'s per-GPU shard (8192 HRTF sources per GPU, 256-tap
+overlap-save, F = 512 @ 48 kHz); at N GPUs the job is 8192*N sources (configs[3] itself at N = 8),
+weak scaling, one process per GPU, partial mixes sum-reduced to rank 0 over RCCL (pipelined one
+callback deep).  `--workload` selects the other configs for ad-hoc runs.
+
+Prints ONE JSON line on rank 0 (contract in the task statement): metric/value/unit, roofline of
+the dominant kernel from HIP events recorded inside the library on its launch stream, and the CPU
+baseline (the oracle's reference-equivalent scalar path, 1 core, bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # name: (kind, chain, frames, default sources per GPU, er ring, description)
+    "hrtf": (2, (3,), 512, 8192, 0, "cfg4 shard: 8192 sources/GPU, 256-tap HRTF overlap-save FFT -> stereo, 512-frame @48kHz"),
+    "hrtf4096": (2, (3,), 512, 4096, 0, "cfg3: 4096 sources, 256-tap HRTF overlap-save FFT -> stereo, 512-frame @48kHz"),
+    "biquad": (0, (), 512, 256, 0, "cfg2: 256 sources, pan + distance high-shelf biquad (mix_channel), 512-frame @48kHz"),
+    "erhrtf": (2, (2, 3), 256, 4096, 4096, "cfg5: 4096 sources, 8-tap early reflections + HRTF chain, 256-frame @48kHz"),
+}
+HBM_PEAK = 8.0e12  # MI355X_MICROARCH.md: 8 TB/s spec
+N_SRC_BUFFERS_BYTES = 320 << 20  # rotate source buffers over > 256 MiB so the Infinity Cache cannot hold them
+
+
+def cpu_baseline(kind, chain, frames, dirs, hrir, ring, budget_s=12.0):
+    """Reference-equivalent CPU path (oracle, scalar f32, 1 core) on a bounded sample of the workload."""
+    from oracle import binding as ob
+    from godot_audio_spatializer_amd import synth
+
+    rng = np.random.default_rng(1234)
+    n = 512 if 3 in chain else 2048
+    ora = ob.BatchOracle(kind, n, frames, chain=chain, hrir=hrir, er_ring_frames=max(ring, 1), hrtf_impl=1)
+    p = synth.draw_params(rng, n, dirs=dirs, ring_frames=max(ring, 2 * frames), frames=frames).astype(ob.PARAMS_DTYPE)
+    src = synth.draw_sources(rng, n, frames)
+    ora.block(p, src)  # warm-up (state, caches)
+    blocks = 0
+    t0 = time.perf_counter()
+    while True:
+        if blocks % 2 == 0:
+            p = synth.draw_params(rng, n, dirs=dirs, ring_frames=max(ring, 2 * frames), frames=frames).astype(ob.PARAMS_DTYPE)
+        t_in = time.perf_counter()
+        ora.block(p, src)
+        blocks += 1
+        if time.perf_counter() - t0 > budget_s or blocks >= 64:
+            break
+    # time only the oracle calls: re-measure precisely over the same number of blocks
+    t1 = time.perf_counter()
+    for _ in range(blocks):
+        ora.block(p, src)
+    dt = time.perf_counter() - t1
+    return {
+        "value": n * frames * blocks / dt,
+        "unit": "AudioFrames/s",
+        "cores": 1,
+        "kind": "port",
+        "sample": f"{n} sources x {blocks} callbacks of the same workload, oracle scalar f32 path (HRTF by radix-2 overlap-save), 1 thread",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="hrtf", choices=sorted(WORKLOADS))
+    ap.add_argument("--sources-per-gpu", type=int, default=0)
+    ap.add_argument("--dirs", type=int, default=1024)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-max-sources", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    import godot_audio_spatializer_amd as gas
+    from godot_audio_spatializer_amd import sharding, synth
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the spatializer has no CPU path")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    kind, chain, frames, n_default, ring, desc = WORKLOADS[args.workload]
+    n_local = args.sources_per_gpu or n_default
+    n_total = n_local * world
+    begin, end = sharding.shard_range(n_total, rank, world)
+    assert end - begin == n_local
+
+    rng = np.random.default_rng(1234)
+    hrir = synth.synthetic_hrir(rng, dirs=args.dirs) if 3 in chain else None
+    ctx = gas.SpatializerContext(max_sources=n_local, frames=frames, channel_count=1, er_ring_frames=ring, device=local_rank)
+    stream = torch.cuda.current_stream()
+    ctx.set_stream(stream.cuda_stream)
+    if hrir is not None:
+        ctx.hrtf_load(hrir)
+    slots = ctx.source_alloc_many(n_local, kind, chain)
+
+    # two physics ticks of parameters, device-resident, alternated every 2 callbacks
+    prng = np.random.default_rng(1234 + 7919 * rank)
+    psets = []
+    for _ in range(2):
+        p = synth.draw_params(prng, n_local, dirs=args.dirs, ring_frames=max(ring, 2 * frames), frames=frames)
+        psets.append(torch.from_numpy(p.view(np.uint8).reshape(n_local, 128).copy()).cuda())
+    ctx.params_publish_batch(slots, synth.draw_params(prng, n_local, dirs=args.dirs, ring_frames=max(ring, 2 * frames), frames=frames))
+
+    # rotating source buffers: synthetic uniform(-0.5, 0.5) AudioFrames, footprint > Infinity Cache
+    buf_bytes = n_local * frames * 8
+    n_bufs = max(2, min(16, -(-N_SRC_BUFFERS_BYTES // buf_bytes)))
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(1234 + rank)
+    srcs = [torch.rand(n_local, frames, 2, device="cuda", generator=gen) - 0.5 for _ in range(n_bufs)]
+    outs = [torch.zeros(1, frames, 2, device="cuda") for _ in range(2)]
+    peaks = torch.zeros(n_local, 2, device="cuda")
+
+    comm_stream = torch.cuda.Stream() if world > 1 else None
+    reducer = sharding.PartialMixReducer(dist if world > 1 else None, root=0, comm_stream=comm_stream)
+    pending = [None, None]
+
+    rc = ctx.process_block_raw(srcs[0].data_ptr(), slots, n_local, frames, outs[0].data_ptr(), peaks.data_ptr(), gas.capi.MEM_DEVICE)
+    if rc != 0:
+        raise SystemExit(f"gas_process_block failed: {rc}")
+    torch.cuda.synchronize()
+
+    def step(k):
+        if k % 2 == 0:
+            ctx.params_publish_device(psets[(k // 2) % 2].data_ptr(), n_local)
+        o = outs[k % 2]
+        reducer.wait(pending[k % 2])  # the buffer's previous reduce must be done before it is rewritten
+        rc = ctx.process_block_raw(srcs[k % n_bufs].data_ptr(), None, n_local, frames, o.data_ptr(), peaks.data_ptr(), gas.capi.MEM_DEVICE)
+        if rc != 0:
+            raise SystemExit(f"gas_process_block failed: {rc}")
+        pending[k % 2] = reducer.reduce(o)
+
+    def drain():
+        for i in range(2):
+            reducer.wait(pending[i])
+            pending[i] = None
+
+    for k in range(args.warmup):
+        step(k)
+    drain()
+    ctx.profile_enable(True)
+    ctx.profile_read(reset=True)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+        torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(k)
+    drain()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+        torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    prof = ctx.profile_read(reset=True)
+    ctx.profile_enable(False)
+    if world > 1:
+        tmax = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    ms_per_step = dt / args.steps * 1e3
+    value = n_total * frames * args.steps / dt
+
+    result = None
+    if rank == 0:
+        k_ms = prof["kernel_ms"] / max(prof["launches"], 1)
+        achieved = prof["bytes_per_launch"] / (k_ms * 1e-3) if k_ms > 0 else 0.0
+        result = {
+            "metric": "mixed AudioFrames/s",
+            "value": value,
+            "unit": "AudioFrames/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": desc,
+                "sources_total": n_total,
+                "sources_per_gpu": n_local,
+                "frames_per_callback": frames,
+                "sample_rate_hz": 48000,
+                "hrir_directions": args.dirs if hrir is not None else 0,
+                "parallelism": f"source-sharded x{world}, RCCL sum-reduce of the 4 KiB partial mix to rank 0" if world > 1 else "single GPU",
+                "realtime_budget_ms": frames / 48000.0 * 1e3,
+            },
+            "roofline": {
+                "bound": "hbm",
+                "achieved": achieved / 1e9,
+                "peak": HBM_PEAK / 1e9,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK,
+                "traffic": None,
+                "kernel": prof["kernel"],
+                "kernel_us": k_ms * 1e3,
+                "launches_timed": prof["launches"],
+                "algorithmic_bytes_per_launch": prof["bytes_per_launch"],
+            },
+        }
+
+    # ---- extras on one GPU: max concurrent sources inside the 10.67 ms callback, CPU baseline ----
+    del srcs
+    ctx.close()
+    torch.cuda.empty_cache()
+    if rank == 0 and world == 1:
+        if not args.no_max_sources and args.workload.startswith("hrtf"):
+            try:
+                result["max_sources_under_10ms"] = probe_max_sources(gas, synth, torch, kind, chain, frames, hrir, args.dirs)
+            except Exception as e:  # the probe must never cost the headline line
+                result["max_sources_under_10ms"] = {"error": str(e)}
+        if not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(kind, chain, frames, args.dirs, hrir, ring)
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def probe_max_sources(gas, synth, torch, kind, chain, frames, hrir, dirs):
+    """Largest N (from a fixed ladder) whose p99 callback time stays under 10 ms on one GPU."""
+    best = None
+    ladder = [1 << 19, 1 << 20, 3 << 19, 1 << 21, 5 << 19, 3 << 20]
+    for n in ladder:
+        ctx = gas.SpatializerContext(max_sources=n, frames=frames, channel_count=1)
+        try:
+            ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+            ctx.hrtf_load(hrir)
+            slots = ctx.source_alloc_many(n, kind, chain)
+            rng = np.random.default_rng(99)
+            ctx.params_publish_batch(slots, synth.draw_params(rng, n, dirs=dirs, frames=frames))
+            src = torch.rand(n, frames, 2, device="cuda") - 0.5
+            out = torch.zeros(1, frames, 2, device="cuda")
+            peaks = torch.zeros(n, 2, device="cuda")
+            ctx.process_block_raw(src.data_ptr(), slots, n, frames, out.data_ptr(), peaks.data_ptr(), 1)
+            torch.cuda.synchronize()
+            times = []
+            for _ in range(24):
+                t0 = time.perf_counter()
+                ctx.process_block_raw(src.data_ptr(), None, n, frames, out.data_ptr(), peaks.data_ptr(), 1)
+                torch.cuda.synchronize()
+                times.append(time.perf_counter() - t0)
+            p99 = float(np.sort(times[4:])[-1]) * 1e3
+            del src, out, peaks
+        finally:
+            ctx.close()
+            torch.cuda.empty_cache()
+        if p99 < 10.0:
+            best = {"sources": n, "p99_callback_ms": p99}
+        else:
+            break
+    return best
+
+
+if __name__ == "__main__":
+    main()

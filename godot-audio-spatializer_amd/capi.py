@@ -128,6 +128,14 @@ def load_library():
             f"{path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950). The spatializer has no CPU fallback."
         )
+    # PyTorch-ROCm wheels bundle their own libamdhip64; two HIP runtimes in one process leave the
+    # second one without devices.  Import torch first (when present) so libgas_amd.so binds to the
+    # runtime torch already loaded (same soname) and streams/pointers can be shared with it.
+    if os.environ.get("GAS_NO_TORCH") != "1":
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
     L = C.CDLL(path)
     vp, u32, i32 = C.c_void_p, C.c_uint32, C.c_int
     L.gas_abi_version.restype = i32

@@ -100,7 +100,7 @@ class PDataEffect(C.Structure):
 
 
 class Hrtf(C.Structure):
-    _fields_ = [("hrir", C.POINTER(C.c_float)), ("dirs", C.c_uint32), ("impl", C.c_int32)]
+    _fields_ = [("hrir", C.POINTER(C.c_float)), ("dirs", C.c_uint32), ("impl", C.c_int32), ("spec", C.POINTER(C.c_float)), ("spec_len", C.c_int32)]
 
 
 class Playback(C.Structure):
@@ -185,6 +185,8 @@ def lib():
     L.gaso_get_mixed_frames.argtypes = [C.POINTER(Instance), C.POINTER(C.POINTER(Params)), C.POINTER(C.POINTER(Playback)), C.c_int, C.c_int, C.c_void_p, C.c_int]
     L.gaso_bus_map.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
     L.gaso_batch_block.argtypes = [C.c_int, C.c_int, C.c_void_p, C.POINTER(BatchState), C.POINTER(Hrtf), C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.gaso_hrtf_prepare.argtypes = [C.POINTER(Hrtf), C.c_int]
+    L.gaso_hrtf_release.argtypes = [C.POINTER(Hrtf)]
     L.gaso_hrtf_ols_radix2.argtypes = [C.POINTER(Params), C.POINTER(FxState), C.POINTER(Hrtf), C.c_void_p, C.c_void_p, C.c_int]
     _lib = L
     return L
@@ -198,7 +200,7 @@ def make_hrtf(hrir, impl=0):
     """hrir: float32 [dirs][2][256]. Returns (Hrtf struct, keepalive)."""
     hrir = np.ascontiguousarray(hrir, dtype=np.float32)
     assert hrir.ndim == 3 and hrir.shape[1] == 2 and hrir.shape[2] == HRTF_TAPS
-    h = Hrtf(hrir.ctypes.data_as(C.POINTER(C.c_float)), hrir.shape[0], impl)
+    h = Hrtf(hrir.ctypes.data_as(C.POINTER(C.c_float)), hrir.shape[0], impl, None, 0)
     h._keep = hrir
     return h
 
@@ -217,6 +219,11 @@ class BatchOracle:
         self.mix_rate = float(mix_rate)
         self.states = (BatchState * n_src)()
         self.hrtf = make_hrtf(hrir, hrtf_impl) if hrir is not None else None
+        if self.hrtf is not None and hrtf_impl == 1:
+            fft_len = 1
+            while fft_len < frames + HRTF_TAPS - 1:
+                fft_len *= 2
+            lib().gaso_hrtf_prepare(C.byref(self.hrtf), fft_len)
         self._rings = []
         for s in range(n_src):
             pd = self.states[s].pdfx

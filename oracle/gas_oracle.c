@@ -650,7 +650,26 @@ void gaso_batch_block(int kind, int channel_count, const gaso_params *params, ga
 /* ------------------------------------------------------------------ */
 /* CPU baseline arithmetic for HRTF: overlap-save, plain radix-2 FFT.   */
 /* ------------------------------------------------------------------ */
+/* Twiddles exp(-2 pi i k / n), k < n/2, computed once per length in f64 (not thread-safe; the
+ * oracle is single-threaded test infrastructure). */
+#define GASO_FFT_MAX 4096
+static float tw_re[GASO_FFT_MAX / 2], tw_im[GASO_FFT_MAX / 2];
+static int tw_n = 0;
+
+static void fft_twiddles(int n) {
+	if (tw_n == n) {
+		return;
+	}
+	for (int k = 0; k < n / 2; k++) {
+		double ang = -2.0 * 3.14159265358979323846 * k / n;
+		tw_re[k] = (float)cos(ang);
+		tw_im[k] = (float)sin(ang);
+	}
+	tw_n = n;
+}
+
 static void fft_radix2(float *re, float *im, int n, int inverse) {
+	fft_twiddles(n);
 	for (int i = 1, j = 0; i < n; i++) {
 		int bit = n >> 1;
 		for (; j & bit; bit >>= 1) {
@@ -667,19 +686,19 @@ static void fft_radix2(float *re, float *im, int n, int inverse) {
 		}
 	}
 	for (int len = 2; len <= n; len <<= 1) {
-		double ang = 2.0 * 3.14159265358979323846 / len * (inverse ? 1.0 : -1.0);
 		int half = len >> 1;
-		for (int k = 0; k < half; k++) {
-			float wr = (float)cos(ang * k);
-			float wi = (float)sin(ang * k);
-			for (int i = k; i < n; i += len) {
-				int j = i + half;
-				float tr = re[j] * wr - im[j] * wi;
-				float ti = re[j] * wi + im[j] * wr;
-				re[j] = re[i] - tr;
-				im[j] = im[i] - ti;
-				re[i] += tr;
-				im[i] += ti;
+		int step = n / len;
+		for (int i = 0; i < n; i += len) {
+			for (int k = 0; k < half; k++) {
+				float wr = tw_re[k * step];
+				float wi = inverse ? -tw_im[k * step] : tw_im[k * step];
+				int a = i + k, b = a + half;
+				float tr = re[b] * wr - im[b] * wi;
+				float ti = re[b] * wi + im[b] * wr;
+				re[b] = re[a] - tr;
+				im[b] = im[a] - ti;
+				re[a] += tr;
+				im[a] += ti;
 			}
 		}
 	}
@@ -704,10 +723,18 @@ void gaso_hrtf_ols_radix2(const gaso_params *params, gaso_fx_state *st, const ga
 	}
 	fft_radix2(xr, xi, L, 0);
 	for (int ear = 0; ear < 2; ear++) {
-		memset(hr, 0, sizeof(float) * (size_t)L);
-		memset(hi, 0, sizeof(float) * (size_t)L);
-		memcpy(hr, h[ear], sizeof(float) * T);
-		fft_radix2(hr, hi, L, 0);
+		if (hrtf->spec && hrtf->spec_len == L) {
+			const float *sp = hrtf->spec + ((size_t)dir * 2 + ear) * 2 * L;
+			hr = (float *)sp;
+			hi = (float *)sp + L;
+		} else {
+			hr = buf + 2 * L;
+			hi = buf + 3 * L;
+			memset(hr, 0, sizeof(float) * (size_t)L);
+			memset(hi, 0, sizeof(float) * (size_t)L);
+			memcpy(hr, h[ear], sizeof(float) * T);
+			fft_radix2(hr, hi, L, 0);
+		}
 		for (int k = 0; k < L; k++) {
 			yr[k] = xr[k] * hr[k] - xi[k] * hi[k];
 			yi[k] = xr[k] * hi[k] + xi[k] * hr[k];
@@ -726,4 +753,25 @@ void gaso_hrtf_ols_radix2(const gaso_params *params, gaso_fx_state *st, const ga
 	hrtf_commit(params, st, xx, n);
 	free(buf);
 	free(xx);
+}
+
+void gaso_hrtf_prepare(gaso_hrtf *hrtf, int L) {
+	const int T = GASO_HRTF_TAPS;
+	gaso_hrtf_release(hrtf);
+	hrtf->spec = (float *)calloc((size_t)hrtf->dirs * 2 * 2 * L, sizeof(float));
+	hrtf->spec_len = L;
+	for (uint32_t d = 0; d < hrtf->dirs; d++) {
+		for (int ear = 0; ear < 2; ear++) {
+			float *re = hrtf->spec + ((size_t)d * 2 + ear) * 2 * L;
+			float *im = re + L;
+			memcpy(re, hrtf->hrir + ((size_t)d * 2 + ear) * T, sizeof(float) * T);
+			fft_radix2(re, im, L, 0);
+		}
+	}
+}
+
+void gaso_hrtf_release(gaso_hrtf *hrtf) {
+	free(hrtf->spec);
+	hrtf->spec = NULL;
+	hrtf->spec_len = 0;
 }

@@ -110,6 +110,8 @@ typedef struct gaso_hrtf {
 	const float *hrir;
 	uint32_t dirs;
 	int32_t impl; /* 0: direct-form f64 FIR (the checker); 1: overlap-save radix-2 FFT in f32 (the CPU baseline) */
+	float *spec; /* impl 1 only: cached HRIR spectra [dirs][2 ears][re|im][spec_len], built by gaso_hrtf_prepare */
+	int32_t spec_len;
 } gaso_hrtf;
 
 /* ---- engine primitives ------------------------------------------------ */
@@ -191,6 +193,9 @@ void gaso_batch_block(int kind, int channel_count, const gaso_params *params, ga
 
 /* HRTF by overlap-save with a plain radix-2 FFT: CPU baseline arithmetic for the
  * HRTF configs, same semantics as GASO_FX_HRTF. */
+/* Precompute (malloc) the HRIR spectra for FFT length L so the baseline does not re-transform taps per source. */
+void gaso_hrtf_prepare(gaso_hrtf *hrtf, int L);
+void gaso_hrtf_release(gaso_hrtf *hrtf);
 void gaso_hrtf_ols_radix2(const gaso_params *params, gaso_fx_state *st, const gaso_hrtf *hrtf, const gaso_frame *src, gaso_frame *dst, int n);
 
 #ifdef __cplusplus
