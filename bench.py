@@ -79,6 +79,7 @@ def main():
     ap.add_argument("--dirs", type=int, default=1024)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-max-sources", action="store_true")
+    ap.add_argument("--exact-peaks", action="store_true", help="per-source inverse FFTs for every source (exact peak of every source)")
     args = ap.parse_args()
 
     import torch
@@ -108,12 +109,21 @@ def main():
 
     rng = np.random.default_rng(1234)
     hrir = synth.synthetic_hrir(rng, dirs=args.dirs) if 3 in chain else None
-    ctx = gas.SpatializerContext(max_sources=n_local, frames=frames, channel_count=1, er_ring_frames=ring, device=local_rank)
+    # Peaks are produced where the reference consumes them: playbacks whose stream has ended
+    # (audio_spatializer.cpp:464-469).  1 source in 64 is in that state here; the rest take the
+    # frequency-domain accumulation path.  --exact-peaks measures every source's peak instead.
+    flags = 0 if args.exact_peaks else gas.capi.FLAG_PEAKS_DRAINING_ONLY
+    ctx = gas.SpatializerContext(max_sources=n_local, frames=frames, channel_count=1, er_ring_frames=ring, device=local_rank, flags=flags)
     stream = torch.cuda.current_stream()
     ctx.set_stream(stream.cuda_stream)
     if hrir is not None:
         ctx.hrtf_load(hrir)
     slots = ctx.source_alloc_many(n_local, kind, chain)
+    n_draining = 0
+    if kind == 2:
+        for s_ in slots[::64]:
+            ctx.source_set_draining(int(s_), True)
+            n_draining += 1
 
     # two physics ticks of parameters, device-resident, alternated every 2 callbacks
     prng = np.random.default_rng(1234 + 7919 * rank)
@@ -208,6 +218,7 @@ def main():
                 "frames_per_callback": frames,
                 "sample_rate_hz": 48000,
                 "hrir_directions": args.dirs if hrir is not None else 0,
+                "peaks": "every source" if args.exact_peaks else f"draining sources only ({n_draining} of {n_local} per GPU)",
                 "parallelism": f"source-sharded x{world}, RCCL sum-reduce of the 4 KiB partial mix to rank 0" if world > 1 else "single GPU",
                 "realtime_budget_ms": frames / 48000.0 * 1e3,
             },
@@ -249,7 +260,7 @@ def probe_max_sources(gas, synth, torch, kind, chain, frames, hrir, dirs):
     best = None
     ladder = [1 << 19, 1 << 20, 3 << 19, 1 << 21, 5 << 19, 3 << 20]
     for n in ladder:
-        ctx = gas.SpatializerContext(max_sources=n, frames=frames, channel_count=1)
+        ctx = gas.SpatializerContext(max_sources=n, frames=frames, channel_count=1, flags=gas.capi.FLAG_PEAKS_DRAINING_ONLY)
         try:
             ctx.set_stream(torch.cuda.current_stream().cuda_stream)
             ctx.hrtf_load(hrir)

@@ -22,6 +22,7 @@ FX_EARLY_REFLECTIONS = 2
 FX_HRTF = 3
 MEM_HOST = 0
 MEM_DEVICE = 1
+FLAG_PEAKS_DRAINING_ONLY = 1
 
 STATUS = {
     0: "GAS_OK",
@@ -92,6 +93,7 @@ EXPORTS = [
     "gas_source_alloc",
     "gas_source_free",
     "gas_source_reset",
+    "gas_source_set_draining",
     "gas_params_publish",
     "gas_params_publish_batch",
     "gas_hrtf_load",
@@ -151,6 +153,7 @@ def load_library():
     L.gas_source_alloc.argtypes = [vp, i32, C.POINTER(C.c_int32), u32, C.POINTER(u32)]
     L.gas_source_free.argtypes = [vp, u32]
     L.gas_source_reset.argtypes = [vp, u32]
+    L.gas_source_set_draining.argtypes = [vp, u32, i32]
     L.gas_params_publish.argtypes = [vp, u32, vp]
     L.gas_params_publish_batch.argtypes = [vp, vp, vp, u32, i32]
     L.gas_hrtf_load.argtypes = [vp, vp, u32, u32]
@@ -170,12 +173,12 @@ def _np_ptr(a):
 class SpatializerContext:
     """Thin object wrapper over one gas_ctx (one GPU)."""
 
-    def __init__(self, max_sources, frames=512, channel_count=1, mix_rate=48000.0, er_ring_frames=0, device=0):
+    def __init__(self, max_sources, frames=512, channel_count=1, mix_rate=48000.0, er_ring_frames=0, device=0, flags=0):
         self.lib = load_library()
         self.frames = int(frames)
         self.channel_count = int(channel_count)
         self.max_sources = int(max_sources)
-        cfg = Config(C.sizeof(Config), device, max_sources, frames, channel_count, mix_rate, er_ring_frames, 0)
+        cfg = Config(C.sizeof(Config), device, max_sources, frames, channel_count, mix_rate, er_ring_frames, flags)
         h = C.c_void_p()
         rc = self.lib.gas_ctx_create(C.byref(cfg), C.byref(h))
         if rc != 0:
@@ -218,6 +221,9 @@ class SpatializerContext:
 
     def source_free(self, slot):
         self._check(self.lib.gas_source_free(self.h, int(slot)), "gas_source_free")
+
+    def source_set_draining(self, slot, draining=True):
+        self._check(self.lib.gas_source_set_draining(self.h, int(slot), int(draining)), "gas_source_set_draining")
 
     def source_reset(self, slot):
         self._check(self.lib.gas_source_reset(self.h, int(slot)), "gas_source_reset")

@@ -18,15 +18,17 @@ enum gas_group_type {
 	G_3D_PROCESS,
 	G_FX_COPY,
 	G_FX_SHELF,
-	G_FX_HRTF,
+	G_FX_HRTF, // frequency-domain accumulation, no per-source peak
 	G_FX_ER,
 	G_FX_ER_HRTF,
+	G_FX_HRTF_PK, // per-source inverse FFTs: exact peaks (draining playbacks / peaks-for-all contexts)
+	G_FX_ER_HRTF_PK,
 	G_COUNT
 };
 
 const char *const k_group_kernel[G_COUNT] = {
 	"k_biquad_mix<MIX_CHANNEL>", "k_biquad_mix<PROCESS_FRAMES>", "k_biquad_mix<COPY>", "k_biquad_mix<FX_HIGHSHELF>",
-	"k_hrtf_ols", "k_er_only", "k_hrtf_ols<ER>"
+	"k_hrtf_ols<fd>", "k_er_only", "k_hrtf_ols<ER,fd>", "k_hrtf_ols<peaks>", "k_hrtf_ols<ER,peaks>"
 };
 
 struct SlotInfo {
@@ -36,6 +38,7 @@ struct SlotInfo {
 	uint8_t has_params = 0;
 	uint8_t pending_free = 0;
 	uint8_t dirty_state = 0; // state must be zeroed before reuse
+	uint8_t draining = 0; // stream ended: the host's silence gate needs this source's peak (audio_spatializer.cpp:464)
 };
 
 struct Group {
@@ -71,7 +74,8 @@ struct gas_ctx {
 	uint32_t *d_upload_slots = nullptr;
 
 	uint32_t *h_idx = nullptr; // pinned [2 * max_sources]: slots then rows, sorted by group
-	uint32_t *d_slots = nullptr, *d_rows = nullptr;
+	uint32_t *d_slots = nullptr, *d_rows = nullptr; // sorted by launch group
+	uint32_t *d_slots_rows = nullptr; // the caller's list in row order (device-side parameter publication)
 	uint32_t cached_n = UINT32_MAX;
 	bool cached_identity_rows = true;
 	Group groups[G_COUNT];
@@ -140,7 +144,7 @@ uint32_t group_partials(int gt, uint32_t n) {
 	if (n == 0) {
 		return 0;
 	}
-	if (gt == G_FX_HRTF || gt == G_FX_ER || gt == G_FX_ER_HRTF) {
+	if (gt >= G_FX_HRTF) {
 		return gas_hrtf_partials(n, nullptr);
 	}
 	return gas_biquad_partials(n);
@@ -163,6 +167,7 @@ uint64_t group_bytes(const gas_ctx *c, int gt, uint32_t n) {
 			S = 8;
 			break;
 		case G_FX_HRTF:
+		case G_FX_HRTF_PK:
 			S = 24; // gain + dir, previous gain r/w, peak
 			H = 2ull * c->hist_len * 4; // history read + write
 			tab = (uint64_t)c->tab.dirs * 2 * GAS_HRTF_TAPS * 4;
@@ -172,6 +177,7 @@ uint64_t group_bytes(const gas_ctx *c, int gt, uint32_t n) {
 			H = (uint64_t)GAS_ER_TAPS * F * 8 + F * 8; // tap gathers + ring write
 			break;
 		case G_FX_ER_HRTF:
+		case G_FX_ER_HRTF_PK:
 			S = 24 + 64 + 8;
 			H = (uint64_t)GAS_ER_TAPS * F * 8 + F * 8 + 2ull * c->hist_len * 4;
 			tab = (uint64_t)c->tab.dirs * 2 * GAS_HRTF_TAPS * 4;
@@ -210,7 +216,12 @@ int run_groups(gas_ctx *c, const gas_audio_frame *d_src, const uint32_t *d_slots
 	if (rc != GAS_OK) {
 		return rc;
 	}
-	if (n_total > 0) {
+	// only k_biquad_mix accumulates peaks (atomicMax over channel pairs); the other kernels store them
+	bool biquad_groups = false;
+	for (int gt = G_3D_MIX; gt <= G_FX_SHELF; gt++) {
+		biquad_groups = biquad_groups || groups[gt].count > 0;
+	}
+	if (biquad_groups) {
 		GAS_HIP(c, hipMemsetAsync(d_peaks, 0, (size_t)n_total * 2 * sizeof(float), c->stream));
 	}
 
@@ -257,10 +268,12 @@ int run_groups(gas_ctx *c, const gas_audio_frame *d_src, const uint32_t *d_slots
 				e = gas_launch_biquad_mix(c->stream, GAS_MODE_FX_HIGHSHELF, ga, c->st, F, 0, 1, c->cfg.mix_rate, c->d_partials, p_off, c->partial_rows);
 				break;
 			case G_FX_HRTF:
-				e = gas_launch_hrtf_ols(c->stream, false, ga, c->st, c->tab, c->d_tw, F, c->hist_len, c->cfg.er_ring_frames, c->d_partials, p_off, c->partial_rows);
+			case G_FX_HRTF_PK:
+				e = gas_launch_hrtf_ols(c->stream, false, gt == G_FX_HRTF_PK, ga, c->st, c->tab, c->d_tw, F, c->hist_len, c->cfg.er_ring_frames, c->d_partials, p_off, c->partial_rows);
 				break;
 			case G_FX_ER_HRTF:
-				e = gas_launch_hrtf_ols(c->stream, true, ga, c->st, c->tab, c->d_tw, F, c->hist_len, c->cfg.er_ring_frames, c->d_partials, p_off, c->partial_rows);
+			case G_FX_ER_HRTF_PK:
+				e = gas_launch_hrtf_ols(c->stream, true, gt == G_FX_ER_HRTF_PK, ga, c->st, c->tab, c->d_tw, F, c->hist_len, c->cfg.er_ring_frames, c->d_partials, p_off, c->partial_rows);
 				break;
 			case G_FX_ER:
 				e = gas_launch_er_only(c->stream, ga, c->st, F, c->cfg.er_ring_frames, c->d_partials, p_off, c->partial_rows);
@@ -322,6 +335,18 @@ int apply_pending_frees(gas_ctx *c) {
 	return GAS_OK;
 }
 
+// HRTF sources take the frequency-domain path unless their peak is needed.
+inline int launch_group(const gas_ctx *c, const SlotInfo &si) {
+	const bool want_peak = si.draining || !(c->cfg.flags & GAS_FLAG_PEAKS_DRAINING_ONLY);
+	if (si.group == G_FX_HRTF && want_peak) {
+		return G_FX_HRTF_PK;
+	}
+	if (si.group == G_FX_ER_HRTF && want_peak) {
+		return G_FX_ER_HRTF_PK;
+	}
+	return si.group;
+}
+
 // Validate + counting-sort the callback's slot list by launch group.
 int build_groups(gas_ctx *c, const uint32_t *slots, uint32_t n) {
 	uint32_t counts[G_COUNT] = { 0 };
@@ -341,7 +366,7 @@ int build_groups(gas_ctx *c, const uint32_t *slots, uint32_t n) {
 			return GAS_ERR_INVALID_ARGUMENT; // one playback twice in a callback would race on its state
 		}
 		c->stamp[s] = c->stamp_gen;
-		counts[c->slots[s].group]++;
+		counts[launch_group(c, c->slots[s])]++;
 	}
 	uint32_t off = 0, cursor[G_COUNT];
 	int nonempty = 0;
@@ -354,7 +379,7 @@ int build_groups(gas_ctx *c, const uint32_t *slots, uint32_t n) {
 	}
 	uint32_t *hs = c->h_idx, *hr = c->h_idx + c->cfg.max_sources;
 	for (uint32_t i = 0; i < n; i++) {
-		const uint32_t p = cursor[c->slots[slots[i]].group]++;
+		const uint32_t p = cursor[launch_group(c, c->slots[slots[i]])]++;
 		hs[p] = slots[i];
 		hr[p] = i;
 	}
@@ -363,6 +388,7 @@ int build_groups(gas_ctx *c, const uint32_t *slots, uint32_t n) {
 		GAS_HIP(c, hipMemcpyAsync(c->d_slots, hs, (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
 		if (!c->cached_identity_rows) {
 			GAS_HIP(c, hipMemcpyAsync(c->d_rows, hr, (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+			GAS_HIP(c, hipMemcpyAsync(c->d_slots_rows, slots, (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
 		}
 		GAS_HIP(c, hipStreamSynchronize(c->stream)); // h_idx is reused by the next list
 	}
@@ -371,7 +397,7 @@ int build_groups(gas_ctx *c, const uint32_t *slots, uint32_t n) {
 }
 
 int needs_hrtf(const gas_ctx *c) {
-	return (c->groups[G_FX_HRTF].count > 0 || c->groups[G_FX_ER_HRTF].count > 0) && c->tab.spec == nullptr;
+	return (c->groups[G_FX_HRTF].count > 0 || c->groups[G_FX_ER_HRTF].count > 0 || c->groups[G_FX_HRTF_PK].count > 0 || c->groups[G_FX_ER_HRTF_PK].count > 0) && c->tab.spec == nullptr;
 }
 
 } // namespace
@@ -442,6 +468,7 @@ void gas_ctx_destroy(gas_ctx *c) {
 	(void)hipFree(c->d_upload_slots);
 	(void)hipFree(c->d_slots);
 	(void)hipFree(c->d_rows);
+	(void)hipFree(c->d_slots_rows);
 	(void)hipFree(c->d_src);
 	(void)hipFree(c->d_out);
 	(void)hipFree(c->d_peaks);
@@ -505,6 +532,7 @@ int gas_ctx_create(const gas_config *cfg, gas_ctx **out_ctx) {
 		GAS_HIP(c, hipMalloc(&c->d_upload_slots, sizeof(uint32_t) * N));
 		GAS_HIP(c, hipMalloc(&c->d_slots, sizeof(uint32_t) * N));
 		GAS_HIP(c, hipMalloc(&c->d_rows, sizeof(uint32_t) * N));
+		GAS_HIP(c, hipMalloc(&c->d_slots_rows, sizeof(uint32_t) * N));
 		GAS_HIP(c, hipMalloc(&c->d_out, sizeof(gas_audio_frame) * cfg->channel_count * cfg->frames));
 		GAS_HIP(c, hipMalloc(&c->d_peaks, sizeof(float) * 2 * N));
 		GAS_HIP(c, hipMalloc(&c->d_one_slot, sizeof(uint32_t)));
@@ -601,6 +629,20 @@ int gas_source_free(gas_ctx *c, uint32_t slot) {
 	return GAS_OK;
 }
 
+int gas_source_set_draining(gas_ctx *c, uint32_t slot, int draining) {
+	if (!c) {
+		return GAS_ERR_INVALID_ARGUMENT;
+	}
+	if (slot >= c->cfg.max_sources || !c->slots[slot].used) {
+		return GAS_ERR_BAD_SLOT;
+	}
+	if (c->slots[slot].draining != (draining != 0)) {
+		c->slots[slot].draining = draining != 0;
+		c->cached_n = UINT32_MAX; // launch groups change: the next callback must pass its slot list again
+	}
+	return GAS_OK;
+}
+
 int gas_source_reset(gas_ctx *c, uint32_t slot) {
 	if (!c) {
 		return GAS_ERR_INVALID_ARGUMENT;
@@ -656,8 +698,7 @@ int gas_params_publish_batch(gas_ctx *c, const uint32_t *slots, const gas_params
 		return GAS_OK;
 	}
 	// Device-resident parameter rows (e.g. produced by a parameter kernel): scatter on the stream.
-	// slots == NULL addresses the slot list of the last gas_process_block, in its row order
-	// when that list was one launch group.
+	// slots == NULL addresses the slot list of the last gas_process_block, in its row order.
 	GAS_HIP(c, hipSetDevice(c->cfg.device));
 	if (slots) {
 		if (n > c->cfg.max_sources) {
@@ -674,10 +715,10 @@ int gas_params_publish_batch(gas_ctx *c, const uint32_t *slots, const gas_params
 		GAS_HIP(c, gas_launch_scatter_params(c->stream, c->st.params, params, c->d_upload_slots, n));
 		GAS_HIP(c, hipStreamSynchronize(c->stream));
 	} else {
-		if (c->cached_n != n || !c->cached_identity_rows) {
+		if (c->cached_n != n) {
 			return GAS_ERR_INVALID_ARGUMENT;
 		}
-		GAS_HIP(c, gas_launch_scatter_params(c->stream, c->st.params, params, c->d_slots, n));
+		GAS_HIP(c, gas_launch_scatter_params(c->stream, c->st.params, params, c->cached_identity_rows ? c->d_slots : c->d_slots_rows, n));
 	}
 	return GAS_OK;
 }
@@ -698,7 +739,7 @@ int gas_hrtf_load(gas_ctx *c, const float *hrir, uint32_t dirs, uint32_t taps) {
 	GAS_HIP(c, hipMalloc(&d_hrir, bytes));
 	int rc = [&]() -> int {
 		GAS_HIP(c, hipMemcpyAsync(d_hrir, hrir, bytes, hipMemcpyHostToDevice, c->stream));
-		GAS_HIP(c, hipMalloc(&c->tab.spec, (size_t)dirs * 8 * 64 * sizeof(float4)));
+		GAS_HIP(c, hipMalloc(&c->tab.spec, (size_t)dirs * 4 * 64 * sizeof(float4))); // bins 0..255, Hermitian half
 		GAS_HIP(c, gas_launch_hrtf_table(c->stream, d_hrir, dirs, taps, c->d_tw, c->tab.spec));
 		GAS_HIP(c, hipStreamSynchronize(c->stream));
 		return GAS_OK;
@@ -826,9 +867,14 @@ static int process_one(gas_ctx *c, uint32_t slot, int channel, bool mix_channel,
 		gt = G_3D_MIX;
 		force_mode = mix_channel ? GAS_MODE_MIX_CHANNEL : GAS_MODE_PROCESS_FRAMES;
 	}
+	if (gt == G_FX_HRTF) {
+		gt = G_FX_HRTF_PK;
+	} else if (gt == G_FX_ER_HRTF) {
+		gt = G_FX_ER_HRTF_PK;
+	}
 	groups[gt].offset = 0;
 	groups[gt].count = 1;
-	if ((gt == G_FX_HRTF || gt == G_FX_ER_HRTF) && c->tab.spec == nullptr) {
+	if ((gt == G_FX_HRTF_PK || gt == G_FX_ER_HRTF_PK) && c->tab.spec == nullptr) {
 		return GAS_ERR_NO_HRTF;
 	}
 	int rc = flush_params(c);

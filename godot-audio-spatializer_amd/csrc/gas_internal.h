@@ -49,7 +49,7 @@ enum gas_biquad_mode {
 };
 
 struct gas_hrtf_table {
-	float4 *spec; // [dirs][8][64] = (HL.re, HL.im, HR.re, HR.im) of bin lane + 64 j, pre-scaled by 1/512
+	float4 *spec; // [dirs][4][64] = (HL.re, HL.im, HR.re, HR.im) of bin lane + 64 j < 256, pre-scaled by 1/512; Nyquist in DC.imag
 	uint32_t dirs;
 };
 
@@ -60,7 +60,7 @@ uint32_t gas_biquad_partials(uint32_t n); // P for n sources
 hipError_t gas_launch_biquad_mix(hipStream_t stream, int mode, const gas_group_args &g, const gas_dev_state &st, uint32_t frames, uint32_t channel_begin, uint32_t channel_count, float mix_rate, float *partials, uint32_t p_offset, uint32_t p_stride);
 
 uint32_t gas_hrtf_partials(uint32_t n, uint32_t *sources_per_wave);
-hipError_t gas_launch_hrtf_ols(hipStream_t stream, bool with_er, const gas_group_args &g, const gas_dev_state &st, const gas_hrtf_table &tab, const float2 *twiddles, uint32_t frames, uint32_t hist_len, uint32_t er_ring_frames, float *partials, uint32_t p_offset, uint32_t p_stride);
+hipError_t gas_launch_hrtf_ols(hipStream_t stream, bool with_er, bool peaks, const gas_group_args &g, const gas_dev_state &st, const gas_hrtf_table &tab, const float2 *twiddles, uint32_t frames, uint32_t hist_len, uint32_t er_ring_frames, float *partials, uint32_t p_offset, uint32_t p_stride);
 hipError_t gas_launch_er_only(hipStream_t stream, const gas_group_args &g, const gas_dev_state &st, uint32_t frames, uint32_t er_ring_frames, float *partials, uint32_t p_offset, uint32_t p_stride);
 
 hipError_t gas_launch_hrtf_table(hipStream_t stream, const float *d_hrir, uint32_t dirs, uint32_t taps, const float2 *twiddles, float4 *spec);

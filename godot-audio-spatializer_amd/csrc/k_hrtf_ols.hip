@@ -25,12 +25,18 @@
 //
 // Bound: HBM.  Algorithmic bytes/source = F*8 (source) + 2*hist_len*4 (history r+w) + 128 (params) + 8
 // (peak) + 8 (gain state), + the ring traffic (8 taps * F * 8 read + F * 8 write) with early reflections.
+#include <cstdlib>
+
 #include "gas_internal.h"
 
 namespace {
 
 constexpr int WAVES = 4;
-constexpr int LDS_F2_PER_WAVE = 8 * 72; // float2 units; exchange 1 uses 8x72, exchange 2 uses 8x66
+#ifndef GAS_HRTF_WAVES_PER_SIMD
+#define GAS_HRTF_WAVES_PER_SIMD 2 // register budget the main kernel is compiled for (VGPR-limited residency)
+#endif
+constexpr int LDS_F2_HALF = 8 * 72; // float2 units; exchange 1 uses 8x72, exchange 2 uses 8x66
+constexpr int LDS_F2_PER_WAVE = 2 * LDS_F2_HALF; // two slices so a pair of transforms can be in flight
 constexpr float S2 = 0.70710678118654752440f;
 
 __device__ __forceinline__ float2 cadd(float2 a, float2 b) {
@@ -125,27 +131,175 @@ __device__ __forceinline__ void fft512(float2 (&v)[8], const float2 (&t1)[8], co
 	dft8<INV>(v);
 }
 
-__device__ __forceinline__ float wave_max(float v) {
+// max over the wave of a NON-NEGATIVE value, on the VALU's DPP data path (no LDS round trips):
+// row_shr 1,2,4,8 leave each 16-lane row's max in its lane 15, row_bcast15 / row_bcast31 fold the
+// rows; zero fill is the identity for non-negative inputs.  Lane 63 holds the result.
+// Two independent 512-point FFTs of one wave, interleaved pass by pass so the LDS exchange of one
+// overlaps the butterflies of the other (lds0 / lds1 are disjoint slices).
+template <bool INV>
+__device__ __forceinline__ void fft512_pair(float2 (&a)[8], float2 (&b)[8], const float2 (&t1)[8], const float2 (&t2)[8], float2 *lds0, float2 *lds1, int lane) {
+	const int hi = lane >> 3, lo = lane & 7;
+	dft8<INV>(a);
 #pragma unroll
-	for (int m = 32; m >= 1; m >>= 1) {
-		float o = __shfl_xor(v, m);
-		v = o > v ? o : v;
+	for (int k = 1; k < 8; k++) {
+		a[k] = INV ? cmulc(a[k], t1[k]) : cmul(a[k], t1[k]);
 	}
-	return v;
+#pragma unroll
+	for (int k = 0; k < 8; k++) {
+		lds0[k * 72 + lane] = a[k];
+	}
+	dft8<INV>(b);
+#pragma unroll
+	for (int k = 1; k < 8; k++) {
+		b[k] = INV ? cmulc(b[k], t1[k]) : cmul(b[k], t1[k]);
+	}
+#pragma unroll
+	for (int k = 0; k < 8; k++) {
+		lds1[k * 72 + lane] = b[k];
+	}
+	wave_lds_sync();
+#pragma unroll
+	for (int k = 0; k < 8; k++) {
+		a[k] = lds0[hi * 72 + k * 8 + lo];
+	}
+#pragma unroll
+	for (int k = 0; k < 8; k++) {
+		b[k] = lds1[hi * 72 + k * 8 + lo];
+	}
+	wave_lds_sync();
+	dft8<INV>(a);
+#pragma unroll
+	for (int k = 0; k < 8; k++) {
+		a[k] = INV ? cmulc(a[k], t2[k]) : cmul(a[k], t2[k]);
+	}
+#pragma unroll
+	for (int k = 0; k < 8; k++) {
+		lds0[lo * 66 + k * 8 + hi] = a[k];
+	}
+	dft8<INV>(b);
+#pragma unroll
+	for (int k = 0; k < 8; k++) {
+		b[k] = INV ? cmulc(b[k], t2[k]) : cmul(b[k], t2[k]);
+	}
+#pragma unroll
+	for (int k = 0; k < 8; k++) {
+		lds1[lo * 66 + k * 8 + hi] = b[k];
+	}
+	wave_lds_sync();
+#pragma unroll
+	for (int k = 0; k < 8; k++) {
+		a[k] = lds0[k * 66 + lane];
+	}
+#pragma unroll
+	for (int k = 0; k < 8; k++) {
+		b[k] = lds1[k * 66 + lane];
+	}
+	wave_lds_sync();
+	dft8<INV>(a);
+	dft8<INV>(b);
+}
+
+__device__ __forceinline__ float wave_max(float v) {
+	int x = __float_as_int(v);
+#define GAS_DPP_MAX(ctrl, row_mask)                                                                    \
+	x = __float_as_int(fmaxf(__int_as_float(x), __int_as_float(__builtin_amdgcn_update_dpp(0, x, ctrl, row_mask, 0xF, false))))
+	GAS_DPP_MAX(0x111, 0xF); // row_shr:1
+	GAS_DPP_MAX(0x112, 0xF); // row_shr:2
+	GAS_DPP_MAX(0x114, 0xF); // row_shr:4
+	GAS_DPP_MAX(0x118, 0xF); // row_shr:8
+	GAS_DPP_MAX(0x142, 0xA); // row_bcast:15 -> rows 1,3
+	GAS_DPP_MAX(0x143, 0xC); // row_bcast:31 -> rows 2,3
+#undef GAS_DPP_MAX
+	return __int_as_float(__builtin_amdgcn_readlane(x, 63));
+}
+
+// Wave-uniform description of one source of the callback (scalar registers).
+struct SrcMeta {
+	uint32_t slot, row, dir;
+	float g0, g1;
+};
+
+// Metadata of a wave's sources lives one-source-per-lane in VGPRs: the dependent loads
+// (slot list -> parameter table -> direction) are paid once per wave, for all of its sources in
+// parallel, instead of once per source on the critical path (dependent scalar loads share lgkmcnt
+// with the FFT's LDS exchanges and cost ~16 us per launch when done per source).
+struct LaneMeta {
+	uint32_t slot, row, dir;
+	float g0, g1;
+};
+
+__device__ __forceinline__ SrcMeta bcast_meta(const LaneMeta &lm, uint32_t i) {
+	SrcMeta m;
+	m.slot = (uint32_t)__builtin_amdgcn_readlane((int)lm.slot, (int)i);
+	m.row = (uint32_t)__builtin_amdgcn_readlane((int)lm.row, (int)i);
+	m.dir = (uint32_t)__builtin_amdgcn_readlane((int)lm.dir, (int)i);
+	m.g0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lm.g0), (int)i));
+	m.g1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lm.g1), (int)i));
+	return m;
+}
+
+// HRIR spectra table: the HRIRs are real, so H[512-k] = conj(H[k]); only bins 0..255 are stored per
+// direction (4 KiB: float4 = HL.re, HL.im, HR.re, HR.im), with the real Nyquist bin H[256] parked in the
+// (zero) imaginary slots of DC.  Lane l needs bins l + 64 j: j < 4 come straight from the table, j >= 4
+// are fetched as bin 512 - k -- the same 4 KiB, mirrored addressing -- and conjugated.  This halves the
+// table footprint (4 MiB at 1024 directions = one XCD L2) and its L2 -> CU traffic per source.
+__device__ __forceinline__ void issue_spectra(const float4 *__restrict__ spec, uint32_t dir, int lane, float4 (&hs)[8]) {
+	const float4 *base = spec + (size_t)dir * 256;
+#pragma unroll
+	for (int j = 0; j < 4; j++) {
+		hs[j] = base[j * 64 + lane];
+	}
+#pragma unroll
+	for (int j = 4; j < 8; j++) {
+		int p = 512 - (lane + 64 * j); // 1..256
+		p = p == 256 ? 0 : p; // lane 0, j = 4: the Nyquist bin lives in DC's imaginary slots
+		hs[j] = base[p];
+	}
+}
+
+// Turns the registers filled by issue_spectra into H[lane + 64 j] for every j.
+__device__ __forceinline__ void finish_spectra(int lane, float4 (&hs)[8]) {
+#pragma unroll
+	for (int j = 4; j < 8; j++) {
+		hs[j].y = -hs[j].y;
+		hs[j].w = -hs[j].w;
+	}
+	if (lane == 0) {
+		hs[4] = make_float4(hs[0].y, 0.0f, hs[0].w, 0.0f);
+		hs[0].y = 0.0f;
+		hs[0].w = 0.0f;
+	}
 }
 
 // SQ = S/64 = F/128: 4 for F = 512, 2 for F = 256.
-template <int SQ, bool WITH_ER>
-__global__ __launch_bounds__(WAVES * 64) void k_hrtf_ols(gas_group_args g, gas_dev_state st, gas_hrtf_table tab, const float2 *__restrict__ tw, uint32_t spw, uint32_t er_R, float *__restrict__ partials, uint32_t p_offset, uint32_t p_stride) {
+//
+// PEAKS = true : every source gets its own pair of inverse FFTs, so its output peak (the input of the
+//                host's silence gate, audio_spatializer.cpp:436-443,464-469) is exact; the wave sums
+//                its sources in the time domain.
+// PEAKS = false: the sum over sources commutes with the inverse transform, so a wave accumulates
+//                Z_s * H_L[d_s] and Z_s * H_R[d_s] in the frequency domain (one forward FFT per source)
+//                and the workgroup runs ONE pair of inverse FFTs at the end.  peaks[] gets +inf
+//                ("not measured": never satisfies the gate).  The context routes a source here unless
+//                it is marked draining (gas_source_set_draining) or peaks were asked for every source.
+//
+// Software pipeline over the wave's sources: while source e runs its FFTs, the frames and history of
+// source e+1 (issued right after e's were consumed) and its HRIR spectra (issued right after e's
+// spectral products) are in flight, so the arithmetic hides the HBM / L2 latency.
+template <int SQ, bool WITH_ER, bool PEAKS>
+__global__ __launch_bounds__(WAVES * 64, GAS_HRTF_WAVES_PER_SIMD) void k_hrtf_ols(gas_group_args g, gas_dev_state st, gas_hrtf_table tab, const float2 *__restrict__ tw, uint32_t spw, uint32_t er_R, float *__restrict__ partials, uint32_t p_offset, uint32_t p_stride) {
 	constexpr int FQ = 2 * SQ; // F / 64
 	constexpr int HQ = 8 - SQ; // hist_len / 64
 	constexpr int NQ = 8 + SQ; // (hist_len + F) / 64
 	constexpr uint32_t F = FQ * 64;
 	constexpr uint32_t HL = HQ * 64;
+	// LDS (float2 units): main loop = one exchange slice pair per wave; the PEAKS=false epilogue re-uses
+	// the front as fd[wave][ear][512] and needs two more exchange slices + the [F][2] output behind it.
+	constexpr int FD_F2 = WAVES * 2 * 512;
+	constexpr int LDS_TOTAL_F2 = PEAKS ? WAVES * LDS_F2_PER_WAVE : FD_F2 + 2 * LDS_F2_HALF + (int)F;
 
-	__shared__ float2 lds_all[WAVES * LDS_F2_PER_WAVE];
+	__shared__ float2 lds_all[LDS_TOTAL_F2];
 	const int lane = threadIdx.x & 63;
-	const int wave = threadIdx.x >> 6;
+	const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 	float2 *lds = lds_all + wave * LDS_F2_PER_WAVE;
 
 	float2 t1[8], t2[8];
@@ -155,51 +309,74 @@ __global__ __launch_bounds__(WAVES * 64) void k_hrtf_ols(gas_group_args g, gas_d
 		t2[k] = tw[lane * 16 + 8 + k];
 	}
 
+	// running sum of this wave's sources: time domain (PEAKS) or frequency domain
 	float accL[FQ], accR[FQ];
+	float2 aYL[8], aYR[8];
 #pragma unroll
 	for (int t = 0; t < FQ; t++) {
 		accL[t] = 0.0f;
 		accR[t] = 0.0f;
 	}
+#pragma unroll
+	for (int j = 0; j < 8; j++) {
+		aYL[j] = make_float2(0.0f, 0.0f);
+		aYR[j] = make_float2(0.0f, 0.0f);
+	}
 
 	const uint32_t first = (blockIdx.x * WAVES + wave) * spw;
 	const uint32_t last = first + spw < g.n ? first + spw : g.n;
-	for (uint32_t e = first; e < last; e++) {
-		const uint32_t slot = g.slots[e];
-		const uint32_t row = g.rows ? g.rows[e] : e;
-		const gas_params *P = st.params + slot;
-		const float g0 = st.hrtf_prev_gain[slot];
-		const float g1 = P->hrtf_gain;
-		uint32_t dir = P->hrtf_dir;
-		dir = dir < tab.dirs ? dir : 0;
 
-		// HRIR spectra of this direction: issue early, consumed after the forward FFT.
-		float4 hs[8];
-#pragma unroll
-		for (int j = 0; j < 8; j++) {
-			hs[j] = tab.spec[((size_t)dir * 8 + j) * 64 + lane];
-		}
-
-		// x_full[lane + 64 q]: q < HQ from the history, the rest from this callback's frames.
-		float xq[NQ];
-		float *hist = st.hrtf_hist + (size_t)slot * HL;
+	// in-flight buffers of the software pipeline
+	float4 hs[8]; // spectra (HL.re, HL.im, HR.re, HR.im) of bins lane + 64 j
+	gas_audio_frame raw[FQ]; // frames lane + 64 q of the source row
+	float rawh[HQ]; // history samples lane + 64 q
+	LaneMeta lm{ 0, 0, 0, 0.0f, 0.0f };
+	if (first + lane < last) { // spw <= 64: one lane per source of this wave
+		const uint32_t e = first + lane;
+		lm.slot = g.slots[e];
+		lm.row = g.rows ? g.rows[e] : e;
+		const gas_params *P = st.params + lm.slot;
+		lm.g0 = st.hrtf_prev_gain[lm.slot];
+		lm.g1 = P->hrtf_gain;
+		const uint32_t d = P->hrtf_dir;
+		lm.dir = d < tab.dirs ? d : 0;
+	}
+	SrcMeta m{};
+	if (first < last) {
+		m = bcast_meta(lm, 0);
 #pragma unroll
 		for (int q = 0; q < HQ; q++) {
-			xq[q] = hist[lane + 64 * q];
-		}
-		const gas_audio_frame *srow = g.src + (size_t)row * F;
-		uint32_t er_pos = 0;
-		gas_audio_frame *ring = nullptr;
-		if constexpr (WITH_ER) {
-			er_pos = st.er_pos[slot];
-			ring = st.er_ring + (size_t)slot * er_R;
+			rawh[q] = st.hrtf_hist[(size_t)m.slot * HL + lane + 64 * q];
 		}
 #pragma unroll
 		for (int q = 0; q < FQ; q++) {
-			const int f = lane + 64 * q;
-			gas_audio_frame fr = srow[f];
-			if constexpr (WITH_ER) {
-				// early reflections (oracle fx_early_reflections): taps in order, f32
+			raw[q] = g.src[(size_t)m.row * F + lane + 64 * q];
+		}
+		issue_spectra(tab.spec, m.dir, lane, hs);
+	}
+
+	for (uint32_t e = first; e < last; e++) {
+		const bool has_next = e + 1 < last;
+		const SrcMeta mn = bcast_meta(lm, has_next ? e + 1 - first : e - first);
+
+		// x_full[lane + 64 q]: q < HQ from the history, the rest from this callback's frames.
+		float xq[NQ];
+#pragma unroll
+		for (int q = 0; q < HQ; q++) {
+			xq[q] = rawh[q];
+		}
+		if constexpr (WITH_ER) {
+			// early reflections (oracle fx_early_reflections): taps in order, f32.  The 64 gathers per
+			// lane run in a rolled loop and hand their result over through the wave's LDS slice.
+			const gas_params *P = st.params + m.slot;
+			const gas_audio_frame *srow = g.src + (size_t)m.row * F;
+			const uint32_t er_pos = st.er_pos[m.slot];
+			gas_audio_frame *ring = st.er_ring + (size_t)m.slot * er_R;
+			float *xs = reinterpret_cast<float *>(lds);
+#pragma unroll 1
+			for (int q = 0; q < FQ; q++) {
+				const int f = lane + 64 * q;
+				gas_audio_frame fr = srow[f];
 				ring[(er_pos + (uint32_t)f) & (er_R - 1)] = fr; // this block into the ring
 				float yl = fr.left, yr = fr.right;
 #pragma unroll
@@ -213,23 +390,47 @@ __global__ __launch_bounds__(WAVES * 64) void k_hrtf_ols(gas_group_args g, gas_d
 					yl = yl + gk * xp.left;
 					yr = yr + gk * xp.right;
 				}
-				fr.left = yl;
-				fr.right = yr;
+				xs[f] = (yl + yr) * 0.5f;
 			}
-			const float mono = (fr.left + fr.right) * 0.5f;
-			const float t = (float)f * (1.0f / (float)F); // F is a power-of-two multiple: exact for 256/512
-			const float gain = g1 * t + (1 - t) * g0;
-			xq[HQ + q] = mono * gain;
+			if (lane == 0) {
+				st.er_pos[m.slot] = (er_pos + F) & (er_R - 1);
+			}
+			wave_lds_sync();
+#pragma unroll
+			for (int q = 0; q < FQ; q++) {
+				const int f = lane + 64 * q;
+				const float t = (float)f * (1.0f / (float)F);
+				xq[HQ + q] = xs[f] * (m.g1 * t + (1 - t) * m.g0);
+			}
+			wave_lds_sync();
+		} else {
+#pragma unroll
+			for (int q = 0; q < FQ; q++) {
+				const int f = lane + 64 * q;
+				const float mono = (raw[q].left + raw[q].right) * 0.5f;
+				const float t = (float)f * (1.0f / (float)F); // exact for F = 128/256/512
+				xq[HQ + q] = mono * (m.g1 * t + (1 - t) * m.g0);
+			}
 		}
 		// new history = x_full[F .. F + HL)
 #pragma unroll
 		for (int q = 0; q < HQ; q++) {
-			hist[lane + 64 * q] = xq[FQ + q];
+			st.hrtf_hist[(size_t)m.slot * HL + lane + 64 * q] = xq[FQ + q];
 		}
 		if (lane == 0) {
-			st.hrtf_prev_gain[slot] = g1;
-			if constexpr (WITH_ER) {
-				st.er_pos[slot] = (er_pos + F) & (er_R - 1);
+			st.hrtf_prev_gain[m.slot] = m.g1;
+		}
+		// raw buffers are free again: start the next source's frames and history
+		if (has_next) {
+#pragma unroll
+			for (int q = 0; q < HQ; q++) {
+				rawh[q] = st.hrtf_hist[(size_t)mn.slot * HL + lane + 64 * q];
+			}
+			if constexpr (!WITH_ER) {
+#pragma unroll
+				for (int q = 0; q < FQ; q++) {
+					raw[q] = g.src[(size_t)mn.row * F + lane + 64 * q];
+				}
 			}
 		}
 
@@ -240,74 +441,130 @@ __global__ __launch_bounds__(WAVES * 64) void k_hrtf_ols(gas_group_args g, gas_d
 			v[j] = make_float2(xq[j], xq[j + SQ]);
 		}
 		fft512<false>(v, t1, t2, lds, lane);
+		finish_spectra(lane, hs);
 
-		float pkl = 0.0f, pkr = 0.0f;
-		{
-			float2 y[8];
+		if constexpr (PEAKS) {
+			float2 yl[8], yr[8];
 #pragma unroll
 			for (int j = 0; j < 8; j++) {
-				y[j] = cmul(v[j], make_float2(hs[j].x, hs[j].y));
+				yl[j] = cmul(v[j], make_float2(hs[j].x, hs[j].y));
+				yr[j] = cmul(v[j], make_float2(hs[j].z, hs[j].w));
 			}
-			fft512<true>(y, t1, t2, lds, lane);
+			// spectra registers are free again: start the next direction's table rows
+			if (has_next) {
+				issue_spectra(tab.spec, mn.dir, lane, hs);
+			}
+			float pkl = 0.0f, pkr = 0.0f;
+			fft512_pair<true>(yl, yr, t1, t2, lds, lds + LDS_F2_HALF, lane);
 			// valid outputs are window positions [512 - S, 512): registers j >= HQ
 #pragma unroll
 			for (int t = 0; t < SQ; t++) {
-				const float oa = y[HQ + t].x, ob = y[HQ + t].y;
+				const float oa = yl[HQ + t].x, ob = yl[HQ + t].y;
 				accL[t] += oa;
 				accL[SQ + t] += ob;
 				pkl = fmaxf(pkl, fmaxf(fabsf(oa), fabsf(ob)));
 			}
-		}
-		{
-			float2 y[8];
-#pragma unroll
-			for (int j = 0; j < 8; j++) {
-				y[j] = cmul(v[j], make_float2(hs[j].z, hs[j].w));
-			}
-			fft512<true>(y, t1, t2, lds, lane);
 #pragma unroll
 			for (int t = 0; t < SQ; t++) {
-				const float oa = y[HQ + t].x, ob = y[HQ + t].y;
+				const float oa = yr[HQ + t].x, ob = yr[HQ + t].y;
 				accR[t] += oa;
 				accR[SQ + t] += ob;
 				pkr = fmaxf(pkr, fmaxf(fabsf(oa), fabsf(ob)));
 			}
+			pkl = wave_max(pkl);
+			pkr = wave_max(pkr);
+			if (lane == 0) {
+				g.peaks[(size_t)m.row * 2] = pkl;
+				g.peaks[(size_t)m.row * 2 + 1] = pkr;
+			}
+		} else {
+#pragma unroll
+			for (int j = 0; j < 8; j++) {
+				const float2 pl = cmul(v[j], make_float2(hs[j].x, hs[j].y));
+				const float2 pr = cmul(v[j], make_float2(hs[j].z, hs[j].w));
+				aYL[j] = cadd(aYL[j], pl);
+				aYR[j] = cadd(aYR[j], pr);
+			}
+			if (has_next) {
+				issue_spectra(tab.spec, mn.dir, lane, hs);
+			}
+			if (lane == 0) {
+				g.peaks[(size_t)m.row * 2] = __builtin_inff();
+				g.peaks[(size_t)m.row * 2 + 1] = __builtin_inff();
+			}
 		}
-		pkl = wave_max(pkl);
-		pkr = wave_max(pkr);
-		if (lane == 0) {
-			g.peaks[(size_t)row * 2] = pkl;
-			g.peaks[(size_t)row * 2 + 1] = pkr;
-		}
+		m = mn;
 	}
 
-	// waves -> one partial mix per workgroup; each wave parks its sum in its own LDS slice
-	wave_lds_sync();
-	float *red = reinterpret_cast<float *>(lds);
-#pragma unroll
-	for (int t = 0; t < FQ; t++) {
-		*reinterpret_cast<float2 *>(red + (lane + 64 * t) * 2) = make_float2(accL[t], accR[t]);
-	}
-	__syncthreads();
 	float *my_partial = partials + ((size_t)p_offset + blockIdx.x) * (F * 2);
-	const float *red_all = reinterpret_cast<const float *>(lds_all);
+	if constexpr (PEAKS) {
+		// waves -> one partial mix per workgroup; each wave parks its sum in its own LDS slice
+		wave_lds_sync();
+		float *red = reinterpret_cast<float *>(lds);
 #pragma unroll
-	for (int r = 0; r < (int)(F * 2) / (WAVES * 64); r++) {
-		const int idx = threadIdx.x + r * WAVES * 64;
-		float s = 0.0f;
-#pragma unroll
-		for (int w = 0; w < WAVES; w++) {
-			s += red_all[w * LDS_F2_PER_WAVE * 2 + idx];
+		for (int t = 0; t < FQ; t++) {
+			*reinterpret_cast<float2 *>(red + (lane + 64 * t) * 2) = make_float2(accL[t], accR[t]);
 		}
-		my_partial[idx] = s;
+		__syncthreads();
+		const float *red_all = reinterpret_cast<const float *>(lds_all);
+#pragma unroll
+		for (int r = 0; r < (int)(F * 2) / (WAVES * 64); r++) {
+			const int idx = threadIdx.x + r * WAVES * 64;
+			float s = 0.0f;
+#pragma unroll
+			for (int w = 0; w < WAVES; w++) {
+				s += red_all[w * LDS_F2_PER_WAVE * 2 + idx];
+			}
+			my_partial[idx] = s;
+		}
+	} else {
+		// spectra of all waves -> fd[wave][ear][j][lane]; then wave 0 transforms the left ear's sum and
+		// wave 1 the right ear's, and the workgroup stores one interleaved time-domain partial.
+		__syncthreads(); // every wave is done with its exchange slice (fd aliases them)
+		float2 *fd = lds_all;
+#pragma unroll
+		for (int j = 0; j < 8; j++) {
+			fd[(wave * 2 + 0) * 512 + j * 64 + lane] = aYL[j];
+			fd[(wave * 2 + 1) * 512 + j * 64 + lane] = aYR[j];
+		}
+		__syncthreads();
+		float *outp = reinterpret_cast<float *>(lds_all + FD_F2 + 2 * LDS_F2_HALF);
+		if (wave < 2) {
+			float2 y[8];
+#pragma unroll
+			for (int j = 0; j < 8; j++) {
+				float2 s = fd[(0 * 2 + wave) * 512 + j * 64 + lane];
+#pragma unroll
+				for (int w = 1; w < WAVES; w++) {
+					s = cadd(s, fd[(w * 2 + wave) * 512 + j * 64 + lane]);
+				}
+				y[j] = s;
+			}
+			fft512<true>(y, t1, t2, lds_all + FD_F2 + wave * LDS_F2_HALF, lane);
+#pragma unroll
+			for (int t = 0; t < SQ; t++) {
+				outp[(lane + 64 * t) * 2 + wave] = y[HQ + t].x;
+				outp[(lane + 64 * (SQ + t)) * 2 + wave] = y[HQ + t].y;
+			}
+		}
+		__syncthreads();
+#pragma unroll
+		for (int r = 0; r < (int)(F * 2) / (WAVES * 64); r++) {
+			const int idx = threadIdx.x + r * WAVES * 64;
+			my_partial[idx] = outp[idx];
+		}
 	}
 	(void)p_stride;
+	(void)accL;
+	(void)accR;
+	(void)aYL;
+	(void)aYR;
 }
 
-// HRIR [dirs][2][taps] -> lane-major spectra table, one wave per (direction, ear), scaled by 1/512
-// so the inverse transform needs no normalisation.
+// HRIR [dirs][2][taps] -> lane-major half-spectra table (see issue_spectra), one wave per (direction, ear),
+// scaled by 1/512 so the inverse transform needs no normalisation.
 __global__ __launch_bounds__(64) void k_hrtf_table(const float *__restrict__ hrir, uint32_t dirs, uint32_t taps, const float2 *__restrict__ tw, float4 *__restrict__ spec) {
-	__shared__ float2 lds[LDS_F2_PER_WAVE];
+	__shared__ float2 lds[LDS_F2_HALF];
 	const int lane = threadIdx.x;
 	const uint32_t dir = blockIdx.x >> 1, ear = blockIdx.x & 1;
 	if (dir >= dirs) {
@@ -329,10 +586,13 @@ __global__ __launch_bounds__(64) void k_hrtf_table(const float *__restrict__ hri
 	fft512<false>(v, t1, t2, lds, lane);
 	float *out = reinterpret_cast<float *>(spec);
 #pragma unroll
-	for (int j = 0; j < 8; j++) {
-		const size_t o = (((size_t)dir * 8 + j) * 64 + lane) * 4 + ear * 2;
+	for (int j = 0; j < 4; j++) { // bins 0..255 only (Hermitian half)
+		const size_t o = (((size_t)dir * 4 + j) * 64 + lane) * 4 + ear * 2;
 		out[o] = v[j].x * (1.0f / 512.0f);
 		out[o + 1] = v[j].y * (1.0f / 512.0f);
+	}
+	if (lane == 0) { // Nyquist bin 256 (lane 0, j = 4) is real: park it in DC's imaginary slot
+		out[((size_t)dir * 4 * 64) * 4 + ear * 2 + 1] = v[4].x * (1.0f / 512.0f);
 	}
 }
 
@@ -423,15 +683,23 @@ void gas_make_twiddles(float2 *host_tw) {
 	}
 }
 
-// Sources per wave: enough waves to fill 256 CUs a few times over, few enough partials that
-// k_mix_reduce stays cheap.
+// Sources per wave: the kernel is resident at GAS_HRTF_WAVES_PER_SIMD waves/SIMD; hand every
+// resident wave the same number of sources so the grid drains in one even pass.  At most 64 per wave
+// (one metadata lane per source); beyond that the grid simply grows.
 uint32_t gas_hrtf_partials(uint32_t n, uint32_t *sources_per_wave) {
-	uint32_t spw = n / (256u * 8u);
+	const uint32_t resident_waves = 256u * 4u * GAS_HRTF_WAVES_PER_SIMD;
+	uint32_t spw = (n + resident_waves - 1) / resident_waves;
 	if (spw < 1) {
 		spw = 1;
 	}
-	if (spw > 16) {
-		spw = 16;
+	if (const char *ov = getenv("GAS_HRTF_SPW")) { // tuning aid
+		const int v = atoi(ov);
+		if (v > 0) {
+			spw = (uint32_t)v;
+		}
+	}
+	if (spw > 64) {
+		spw = 64;
 	}
 	if (sources_per_wave) {
 		*sources_per_wave = spw;
@@ -440,7 +708,7 @@ uint32_t gas_hrtf_partials(uint32_t n, uint32_t *sources_per_wave) {
 	return (n + per_wg - 1) / per_wg;
 }
 
-hipError_t gas_launch_hrtf_ols(hipStream_t stream, bool with_er, const gas_group_args &g, const gas_dev_state &st, const gas_hrtf_table &tab, const float2 *twiddles, uint32_t frames, uint32_t hist_len, uint32_t er_ring_frames, float *partials, uint32_t p_offset, uint32_t p_stride) {
+hipError_t gas_launch_hrtf_ols(hipStream_t stream, bool with_er, bool peaks, const gas_group_args &g, const gas_dev_state &st, const gas_hrtf_table &tab, const float2 *twiddles, uint32_t frames, uint32_t hist_len, uint32_t er_ring_frames, float *partials, uint32_t p_offset, uint32_t p_stride) {
 	if (g.n == 0) {
 		return hipSuccess;
 	}
@@ -450,13 +718,19 @@ hipError_t gas_launch_hrtf_ols(hipStream_t stream, bool with_er, const gas_group
 	uint32_t spw = 1;
 	const uint32_t wgs = gas_hrtf_partials(g.n, &spw);
 	dim3 grid(wgs), block(WAVES * 64);
-#define GAS_HRTF_CASE(SQv)                                                                                                               \
-	case SQv:                                                                                                                            \
-		if (with_er) {                                                                                                                   \
-			hipLaunchKernelGGL((k_hrtf_ols<SQv, true>), grid, block, 0, stream, g, st, tab, twiddles, spw, er_ring_frames, partials, p_offset, p_stride);  \
-		} else {                                                                                                                         \
-			hipLaunchKernelGGL((k_hrtf_ols<SQv, false>), grid, block, 0, stream, g, st, tab, twiddles, spw, er_ring_frames, partials, p_offset, p_stride); \
-		}                                                                                                                                \
+#define GAS_HRTF_LAUNCH(SQv, ERv, PKv) \
+	hipLaunchKernelGGL((k_hrtf_ols<SQv, ERv, PKv>), grid, block, 0, stream, g, st, tab, twiddles, spw, er_ring_frames, partials, p_offset, p_stride)
+#define GAS_HRTF_CASE(SQv)                        \
+	case SQv:                                     \
+		if (with_er && peaks) {                   \
+			GAS_HRTF_LAUNCH(SQv, true, true);     \
+		} else if (with_er) {                     \
+			GAS_HRTF_LAUNCH(SQv, true, false);    \
+		} else if (peaks) {                       \
+			GAS_HRTF_LAUNCH(SQv, false, true);    \
+		} else {                                  \
+			GAS_HRTF_LAUNCH(SQv, false, false);   \
+		}                                         \
 		break;
 	switch (frames / 128) {
 		GAS_HRTF_CASE(1)
@@ -467,6 +741,7 @@ hipError_t gas_launch_hrtf_ols(hipStream_t stream, bool with_er, const gas_group
 			return hipErrorInvalidValue;
 	}
 #undef GAS_HRTF_CASE
+#undef GAS_HRTF_LAUNCH
 	return hipGetLastError();
 }
 

@@ -89,8 +89,16 @@ typedef struct gas_config {
 	uint32_t channel_count; /* C: AudioServer channel pairs, 1..4 (audio_spatializer.cpp:172-179) */
 	float mix_rate; /* AudioServer::get_mix_rate(), e.g. 48000 */
 	uint32_t er_ring_frames; /* early-reflection ring length per source (power of two, 0 = effect unavailable) */
-	uint32_t flags; /* reserved, 0 */
+	uint32_t flags; /* GAS_FLAG_* */
 } gas_config;
+
+/* gas_config.flags */
+/* The reference computes every playback's output peak but only reads it once the stream has ended
+ * (audio_spatializer.cpp:464-469).  With this flag HRTF sources that are NOT marked draining are summed
+ * in the frequency domain (one forward FFT per source, inverse FFTs per workgroup) and report
+ * peak = +inf ("not measured", never passes the gate); the mix is unchanged.  Without it every source
+ * reports its exact peak, as the reference computes it. */
+#define GAS_FLAG_PEAKS_DRAINING_ONLY 1u
 
 /* SpatializerParameters (spatializer_parameters.h:39-67) + SpatializerParameters3D
  * (audio_spatializer_3d.h:61-83) as one 128-byte POD, plus the per-block effect
@@ -134,6 +142,9 @@ const char *gas_last_device_error(gas_ctx *ctx);
 int gas_source_alloc(gas_ctx *ctx, int kind, const int32_t *effects, uint32_t n_effects, uint32_t *out_slot);
 int gas_source_free(gas_ctx *ctx, uint32_t slot); /* takes effect at the next block boundary */
 int gas_source_reset(gas_ctx *ctx, uint32_t slot); /* zero the slot's DSP state (a restarted playback) */
+/* has_frames cleared (audio_spatializer.cpp:398): from now on the host reads this source's peak.  Changing the
+ * flag invalidates the cached slot list: pass `slots` to the next gas_process_block. */
+int gas_source_set_draining(gas_ctx *ctx, uint32_t slot, int draining);
 
 /* ---- set_spatializer_parameters (audio_spatializer.cpp:558-564): latest wins,
  * snapshotted once at the start of the next gas_process_block (:328) ------ */

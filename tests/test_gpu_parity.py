@@ -101,3 +101,37 @@ def test_er_hrtf_cfg5(gas, ob):
 
 def test_er_only(gas, ob):
     run_pair(gas, ob, gas.capi.KIND_EFFECT, (gas.capi.FX_EARLY_REFLECTIONS,), 50, 256, 20, ring=4096, redraw_every=3)
+
+
+@pytest.mark.parametrize("frames,chain,ring", [(512, (3,), 0), (256, (3,), 0), (256, (2, 3), 4096)])
+def test_hrtf_frequency_domain_path(gas, ob, frames, chain, ring):
+    """GAS_FLAG_PEAKS_DRAINING_ONLY: non-draining sources are summed in the frequency domain.  The mix must
+    match the oracle exactly as before; draining sources report exact peaks, the others +inf."""
+    from godot_audio_spatializer_amd import synth
+
+    rng = np.random.default_rng(3)
+    n = 150
+    hrir = synth.synthetic_hrir(np.random.default_rng(7), dirs=64)
+    ctx = gas.SpatializerContext(max_sources=n, frames=frames, er_ring_frames=ring, flags=gas.capi.FLAG_PEAKS_DRAINING_ONLY)
+    ctx.hrtf_load(hrir)
+    slots = ctx.source_alloc_many(n, gas.capi.KIND_EFFECT, chain)
+    draining = np.zeros(n, bool)
+    ora = ob.BatchOracle(ob.KIND_EFFECT, n, frames, chain=chain, hrir=hrir, er_ring_frames=max(ring, 1))
+    for b in range(6):
+        if b == 2:  # some streams end: their peaks become observable
+            draining[::7] = True
+            for s in slots[draining]:
+                ctx.source_set_draining(s, True)
+        if b == 4:
+            ctx.source_set_draining(slots[7], False)
+            draining[7] = False
+        if b % 2 == 0:
+            p = synth.draw_params(rng, n, dirs=64, ring_frames=max(ring, 2 * frames), frames=frames)
+            ctx.params_publish_batch(slots, p)
+        src = synth.draw_sources(rng, n, frames)
+        mix, peaks = ctx.process_block(src, slots)
+        _, rpeaks, r64 = ora.block(p.astype(ob.PARAMS_DTYPE), src, want64=True)
+        assert rel_rms(mix[0], r64[0]) <= TOL
+        np.testing.assert_allclose(peaks[draining], rpeaks[draining], rtol=2e-5, atol=1e-7)
+        assert np.all(np.isposinf(peaks[~draining]))
+    ctx.close()

@@ -1,0 +1,17 @@
+#!/bin/bash
+# Collects the rocprofv3 evidence for bench.py's dominant kernel: one kernel-trace/stats run and two
+# separate PMC passes (FETCH_SIZE and WRITE_SIZE do not fit one pass, MI355X_MICROARCH.md PMC slots).
+# Usage (on the GPU box, from the repo root): tools/profile_bench.sh <tag> [bench args...]
+set -e
+TAG=${1:-r01}; shift || true
+REPO=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$REPO/gpurun_out/prof_$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+ARGS="--steps 200 --warmup 20 --no-cpu-baseline --no-max-sources $@"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- python3 $REPO/bench.py $ARGS > $OUT/trace.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch -o fetch -- python3 $REPO/bench.py $ARGS > $OUT/fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write -o write -- python3 $REPO/bench.py $ARGS > $OUT/write.log 2>&1
+cd $REPO
+python3 tools/summarize_profile.py $OUT > $OUT/summary.txt
+cat $OUT/summary.txt
