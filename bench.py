@@ -79,6 +79,7 @@ def main():
     ap.add_argument("--dirs", type=int, default=1024)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-max-sources", action="store_true")
+    ap.add_argument("--profile-every", type=int, default=4, help="bracket the dominant kernel of every Nth step with HIP events (markers cost ~2 us each)")
     ap.add_argument("--exact-peaks", action="store_true", help="per-source inverse FFTs for every source (exact peak of every source)")
     args = ap.parse_args()
 
@@ -169,7 +170,7 @@ def main():
     for k in range(args.warmup):
         step(k)
     drain()
-    ctx.profile_enable(True)
+    ctx.profile_enable(args.profile_every)
     ctx.profile_read(reset=True)
     torch.cuda.synchronize()
     if world > 1:

@@ -291,7 +291,7 @@ class SpatializerContext:
     def synchronize(self):
         self._check(self.lib.gas_ctx_synchronize(self.h), "gas_ctx_synchronize")
 
-    def profile_enable(self, on=True):
+    def profile_enable(self, on=1):
         self._check(self.lib.gas_profile_enable(self.h, int(on)), "gas_profile_enable")
 
     def profile_read(self, reset=True):

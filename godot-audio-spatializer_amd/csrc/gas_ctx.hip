@@ -18,17 +18,17 @@ enum gas_group_type {
 	G_3D_PROCESS,
 	G_FX_COPY,
 	G_FX_SHELF,
-	G_FX_HRTF, // frequency-domain accumulation, no per-source peak
 	G_FX_ER,
+	G_FX_HRTF, // frequency-domain accumulation, no per-source peak
+	G_FX_HRTF_PK, // per-source inverse FFTs: exact peaks (draining playbacks / peaks-for-all contexts); launched with G_FX_HRTF
 	G_FX_ER_HRTF,
-	G_FX_HRTF_PK, // per-source inverse FFTs: exact peaks (draining playbacks / peaks-for-all contexts)
-	G_FX_ER_HRTF_PK,
+	G_FX_ER_HRTF_PK, // launched with G_FX_ER_HRTF
 	G_COUNT
 };
 
 const char *const k_group_kernel[G_COUNT] = {
 	"k_biquad_mix<MIX_CHANNEL>", "k_biquad_mix<PROCESS_FRAMES>", "k_biquad_mix<COPY>", "k_biquad_mix<FX_HIGHSHELF>",
-	"k_hrtf_ols<fd>", "k_er_only", "k_hrtf_ols<ER,fd>", "k_hrtf_ols<peaks>", "k_hrtf_ols<ER,peaks>"
+	"k_er_only", "k_hrtf_ols", "k_hrtf_ols", "k_hrtf_ols<ER>", "k_hrtf_ols<ER>"
 };
 
 struct SlotInfo {
@@ -97,6 +97,8 @@ struct gas_ctx {
 	double prof_ms = 0.0;
 	uint64_t prof_bytes = 0;
 	int prof_group = -1;
+	double ev_overhead_ms = 0.0; // marker/dispatch overhead of an event pair around one launch (calibrated)
+	uint32_t prof_every = 1, prof_tick = 0; // bracket every Nth callback's dominant launch
 
 	std::string last_err;
 };
@@ -140,14 +142,21 @@ int group_of(int kind, const int32_t *fx, uint32_t n_fx) {
 	return -2; // a chain without a fused kernel yet
 }
 
-uint32_t group_partials(int gt, uint32_t n) {
-	if (n == 0) {
-		return 0;
+// Partial mixes each launch group writes (must mirror the launchers' grids).
+void plan_partials(const Group *groups, uint32_t *pcount) {
+	for (int gt = 0; gt < G_COUNT; gt++) {
+		pcount[gt] = 0;
 	}
-	if (gt >= G_FX_HRTF) {
-		return gas_hrtf_partials(n, nullptr);
+	for (int gt = G_3D_MIX; gt <= G_FX_SHELF; gt++) {
+		pcount[gt] = groups[gt].count ? gas_biquad_partials(groups[gt].count) : 0;
 	}
-	return gas_biquad_partials(n);
+	pcount[G_FX_ER] = groups[G_FX_ER].count ? gas_hrtf_partials(groups[G_FX_ER].count, nullptr) : 0;
+	for (int gt : { (int)G_FX_HRTF, (int)G_FX_ER_HRTF }) {
+		gas_hrtf_launch_plan p;
+		gas_hrtf_plan(groups[gt].count, groups[gt + 1].count, &p);
+		pcount[gt] = p.wgs_fd;
+		pcount[gt + 1] = p.wgs_pk;
+	}
 }
 
 // B = N*F*8 + N*S + N*H + B_tab + C*F*8 (compulsory bytes of one launch group).
@@ -205,9 +214,11 @@ int ensure_partials(gas_ctx *c, uint32_t rows) {
 // Device work of one callback over already-grouped entries.
 int run_groups(gas_ctx *c, const gas_audio_frame *d_src, const uint32_t *d_slots, const uint32_t *d_rows, const Group *groups, uint32_t n_total, gas_audio_frame *d_out, float *d_peaks, uint32_t channel_begin, uint32_t channel_count, int force_mode) {
 	const uint32_t F = c->cfg.frames;
+	uint32_t pcount[G_COUNT];
+	plan_partials(groups, pcount);
 	uint32_t p_total = 0, p_mix = 0;
 	for (int gt = 0; gt < G_COUNT; gt++) {
-		p_total += group_partials(gt, groups[gt].count);
+		p_total += pcount[gt];
 		if (gt == G_3D_MIX) {
 			p_mix = p_total;
 		}
@@ -232,6 +243,9 @@ int run_groups(gas_ctx *c, const gas_audio_frame *d_src, const uint32_t *d_slots
 			dom = gt;
 		}
 	}
+	if ((dom == G_FX_HRTF_PK || dom == G_FX_ER_HRTF_PK) && groups[dom - 1].count > 0) {
+		dom = dom - 1; // one launch covers both
+	}
 
 	uint32_t p_off = 0;
 	for (int gt = 0; gt < G_COUNT; gt++) {
@@ -245,7 +259,7 @@ int run_groups(gas_ctx *c, const gas_audio_frame *d_src, const uint32_t *d_slots
 		ga.slots = d_slots + gr.offset;
 		ga.n = gr.count;
 		ga.peaks = d_peaks;
-		const bool timed = c->profiling && gt == dom && c->ev_used + 2 <= c->ev.size();
+		const bool timed = c->profiling && gt == dom && c->ev_used + 2 <= c->ev.size() && (c->prof_tick++ % c->prof_every) == 0;
 		if (timed) {
 			GAS_HIP(c, hipEventRecord(c->ev[c->ev_used], c->stream));
 		}
@@ -267,14 +281,27 @@ int run_groups(gas_ctx *c, const gas_audio_frame *d_src, const uint32_t *d_slots
 			case G_FX_SHELF:
 				e = gas_launch_biquad_mix(c->stream, GAS_MODE_FX_HIGHSHELF, ga, c->st, F, 0, 1, c->cfg.mix_rate, c->d_partials, p_off, c->partial_rows);
 				break;
-			case G_FX_HRTF:
 			case G_FX_HRTF_PK:
-				e = gas_launch_hrtf_ols(c->stream, false, gt == G_FX_HRTF_PK, ga, c->st, c->tab, c->d_tw, F, c->hist_len, c->cfg.er_ring_frames, c->d_partials, p_off, c->partial_rows);
-				break;
-			case G_FX_ER_HRTF:
 			case G_FX_ER_HRTF_PK:
-				e = gas_launch_hrtf_ols(c->stream, true, gt == G_FX_ER_HRTF_PK, ga, c->st, c->tab, c->d_tw, F, c->hist_len, c->cfg.er_ring_frames, c->d_partials, p_off, c->partial_rows);
-				break;
+				if (groups[gt - 1].count > 0) {
+					break; // rode along with the frequency-domain group's launch
+				}
+				[[fallthrough]];
+			case G_FX_HRTF:
+			case G_FX_ER_HRTF: {
+				const bool is_pk = gt == G_FX_HRTF_PK || gt == G_FX_ER_HRTF_PK;
+				const int fd_gt = is_pk ? gt - 1 : gt;
+				const Group &gp = groups[fd_gt + 1];
+				gas_group_args g_fd = ga, g_pk = ga;
+				if (is_pk) {
+					g_fd.n = 0;
+				} else {
+					g_pk.rows = d_rows ? d_rows + gp.offset : nullptr;
+					g_pk.slots = d_slots + gp.offset;
+					g_pk.n = gp.count;
+				}
+				e = gas_launch_hrtf_ols(c->stream, fd_gt == G_FX_ER_HRTF, g_fd, g_pk, c->st, c->tab, c->d_tw, F, c->hist_len, c->cfg.er_ring_frames, c->d_partials, p_off);
+			} break;
 			case G_FX_ER:
 				e = gas_launch_er_only(c->stream, ga, c->st, F, c->cfg.er_ring_frames, c->d_partials, p_off, c->partial_rows);
 				break;
@@ -284,9 +311,13 @@ int run_groups(gas_ctx *c, const gas_audio_frame *d_src, const uint32_t *d_slots
 			GAS_HIP(c, hipEventRecord(c->ev[c->ev_used + 1], c->stream));
 			c->ev_used += 2;
 			c->prof_bytes = group_bytes(c, gt, gr.count);
+			if ((gt == G_FX_HRTF || gt == G_FX_ER_HRTF) && groups[gt + 1].count > 0) {
+				// the exact-peak sources ride in the same launch: add their per-source bytes (table/mix terms counted once)
+				c->prof_bytes += group_bytes(c, gt + 1, groups[gt + 1].count) - group_bytes(c, gt + 1, 0);
+			}
 			c->prof_group = gt;
 		}
-		p_off += group_partials(gt, gr.count);
+		p_off += pcount[gt];
 	}
 
 	// channel pair 0 sums every group's partials; pairs > 0 only the mix_channel group's (which come first)
@@ -920,7 +951,27 @@ int gas_profile_enable(gas_ctx *c, int on) {
 			GAS_HIP(c, hipEventCreate(&e));
 		}
 	}
+	if (on) {
+		// An event pair around a launch reads the kernel plus marker/dispatch overhead.  Calibrate that
+		// overhead with an empty kernel (minimum of 16 tries; the empty dispatch's own sub-microsecond
+		// execution is left in, so the corrected figure errs on the slow side) -- with it the event
+		// figure tracks the rocprofv3 kernel trace of the same run to within ~5-10 %.
+		GAS_HIP(c, hipStreamSynchronize(c->stream));
+		double best = 1e9;
+		for (int i = 0; i < 16; i++) {
+			GAS_HIP(c, hipEventRecord(c->ev[0], c->stream));
+			GAS_HIP(c, gas_launch_noop(c->stream));
+			GAS_HIP(c, hipEventRecord(c->ev[1], c->stream));
+			GAS_HIP(c, hipEventSynchronize(c->ev[1]));
+			float ms = 0.0f;
+			GAS_HIP(c, hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
+			best = ms < best ? ms : best;
+		}
+		c->ev_overhead_ms = best;
+	}
 	c->profiling = on != 0;
+	c->prof_every = on > 1 ? (uint32_t)on : 1; // on = N > 1: bracket every Nth callback only (the markers cost throughput)
+	c->prof_tick = 0;
 	return GAS_OK;
 }
 
@@ -933,7 +984,7 @@ int gas_profile_read(gas_ctx *c, gas_profile *out, int reset) {
 	for (uint32_t i = 0; i + 1 < c->ev_used; i += 2) {
 		float ms = 0.0f;
 		GAS_HIP(c, hipEventElapsedTime(&ms, c->ev[i], c->ev[i + 1]));
-		c->prof_ms += ms;
+		c->prof_ms += ms > c->ev_overhead_ms ? ms - c->ev_overhead_ms : 0.0;
 		c->prof_launches++;
 	}
 	c->ev_used = 0;

@@ -59,8 +59,13 @@ struct gas_hrtf_table {
 uint32_t gas_biquad_partials(uint32_t n); // P for n sources
 hipError_t gas_launch_biquad_mix(hipStream_t stream, int mode, const gas_group_args &g, const gas_dev_state &st, uint32_t frames, uint32_t channel_begin, uint32_t channel_count, float mix_rate, float *partials, uint32_t p_offset, uint32_t p_stride);
 
-uint32_t gas_hrtf_partials(uint32_t n, uint32_t *sources_per_wave);
-hipError_t gas_launch_hrtf_ols(hipStream_t stream, bool with_er, bool peaks, const gas_group_args &g, const gas_dev_state &st, const gas_hrtf_table &tab, const float2 *twiddles, uint32_t frames, uint32_t hist_len, uint32_t er_ring_frames, float *partials, uint32_t p_offset, uint32_t p_stride);
+struct gas_hrtf_launch_plan {
+	uint32_t spw_fd, spw_pk; // sources per wave
+	uint32_t wgs_fd, wgs_pk; // workgroups = partial mixes written
+};
+void gas_hrtf_plan(uint32_t n_fd, uint32_t n_pk, gas_hrtf_launch_plan *plan);
+uint32_t gas_hrtf_partials(uint32_t n, uint32_t *sources_per_wave); // plan for a single-path launch (k_er_only)
+hipError_t gas_launch_hrtf_ols(hipStream_t stream, bool with_er, const gas_group_args &g_fd, const gas_group_args &g_pk, const gas_dev_state &st, const gas_hrtf_table &tab, const float2 *twiddles, uint32_t frames, uint32_t hist_len, uint32_t er_ring_frames, float *partials, uint32_t p_offset);
 hipError_t gas_launch_er_only(hipStream_t stream, const gas_group_args &g, const gas_dev_state &st, uint32_t frames, uint32_t er_ring_frames, float *partials, uint32_t p_offset, uint32_t p_stride);
 
 hipError_t gas_launch_hrtf_table(hipStream_t stream, const float *d_hrir, uint32_t dirs, uint32_t taps, const float2 *twiddles, float4 *spec);
@@ -68,4 +73,5 @@ void gas_make_twiddles(float2 *host_tw /* [64][16] */);
 
 hipError_t gas_launch_mix_reduce(hipStream_t stream, const float *partials, uint32_t p_count, uint32_t p_stride, uint32_t channels, uint32_t frames, gas_audio_frame *out);
 hipError_t gas_launch_scatter_params(hipStream_t stream, gas_params *table, const gas_params *upload, const uint32_t *slots, uint32_t n);
+hipError_t gas_launch_noop(hipStream_t stream); // event-timer calibration
 hipError_t gas_launch_zero_slot(hipStream_t stream, const gas_dev_state &st, uint32_t slot, uint32_t hist_len, uint32_t er_ring_frames);

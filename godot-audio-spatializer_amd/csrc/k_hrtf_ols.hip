@@ -31,7 +31,7 @@
 
 namespace {
 
-constexpr int WAVES = 4;
+constexpr int WAVES = 8; // one workgroup = the CU's whole residency at 2 waves/SIMD -> fewest partial mixes
 #ifndef GAS_HRTF_WAVES_PER_SIMD
 #define GAS_HRTF_WAVES_PER_SIMD 2 // register budget the main kernel is compiled for (VGPR-limited residency)
 #endif
@@ -285,8 +285,15 @@ __device__ __forceinline__ void finish_spectra(int lane, float4 (&hs)[8]) {
 // Software pipeline over the wave's sources: while source e runs its FFTs, the frames and history of
 // source e+1 (issued right after e's were consumed) and its HRIR spectra (issued right after e's
 // spectral products) are in flight, so the arithmetic hides the HBM / L2 latency.
+template <int SQ, bool PEAKS>
+struct HrtfLds {
+	static constexpr int F = 2 * SQ * 64;
+	static constexpr int FD_F2 = WAVES * 2 * 512;
+	static constexpr int TOTAL_F2 = PEAKS ? WAVES * LDS_F2_PER_WAVE : (FD_F2 + 2 * LDS_F2_HALF + F > WAVES * LDS_F2_PER_WAVE ? FD_F2 + 2 * LDS_F2_HALF + F : WAVES * LDS_F2_PER_WAVE);
+};
+
 template <int SQ, bool WITH_ER, bool PEAKS>
-__global__ __launch_bounds__(WAVES * 64, GAS_HRTF_WAVES_PER_SIMD) void k_hrtf_ols(gas_group_args g, gas_dev_state st, gas_hrtf_table tab, const float2 *__restrict__ tw, uint32_t spw, uint32_t er_R, float *__restrict__ partials, uint32_t p_offset, uint32_t p_stride) {
+__device__ __forceinline__ void hrtf_body(float2 *lds_all, const uint32_t wg, const gas_group_args &g, const gas_dev_state &st, const gas_hrtf_table &tab, const float2 *__restrict__ tw, uint32_t spw, uint32_t er_R, float *__restrict__ my_partial) {
 	constexpr int FQ = 2 * SQ; // F / 64
 	constexpr int HQ = 8 - SQ; // hist_len / 64
 	constexpr int NQ = 8 + SQ; // (hist_len + F) / 64
@@ -294,10 +301,7 @@ __global__ __launch_bounds__(WAVES * 64, GAS_HRTF_WAVES_PER_SIMD) void k_hrtf_ol
 	constexpr uint32_t HL = HQ * 64;
 	// LDS (float2 units): main loop = one exchange slice pair per wave; the PEAKS=false epilogue re-uses
 	// the front as fd[wave][ear][512] and needs two more exchange slices + the [F][2] output behind it.
-	constexpr int FD_F2 = WAVES * 2 * 512;
-	constexpr int LDS_TOTAL_F2 = PEAKS ? WAVES * LDS_F2_PER_WAVE : FD_F2 + 2 * LDS_F2_HALF + (int)F;
-
-	__shared__ float2 lds_all[LDS_TOTAL_F2];
+	constexpr int FD_F2 = HrtfLds<SQ, PEAKS>::FD_F2;
 	const int lane = threadIdx.x & 63;
 	const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 	float2 *lds = lds_all + wave * LDS_F2_PER_WAVE;
@@ -323,7 +327,7 @@ __global__ __launch_bounds__(WAVES * 64, GAS_HRTF_WAVES_PER_SIMD) void k_hrtf_ol
 		aYR[j] = make_float2(0.0f, 0.0f);
 	}
 
-	const uint32_t first = (blockIdx.x * WAVES + wave) * spw;
+	const uint32_t first = (wg * WAVES + wave) * spw;
 	const uint32_t last = first + spw < g.n ? first + spw : g.n;
 
 	// in-flight buffers of the software pipeline
@@ -496,7 +500,6 @@ __global__ __launch_bounds__(WAVES * 64, GAS_HRTF_WAVES_PER_SIMD) void k_hrtf_ol
 		m = mn;
 	}
 
-	float *my_partial = partials + ((size_t)p_offset + blockIdx.x) * (F * 2);
 	if constexpr (PEAKS) {
 		// waves -> one partial mix per workgroup; each wave parks its sum in its own LDS slice
 		wave_lds_sync();
@@ -507,9 +510,7 @@ __global__ __launch_bounds__(WAVES * 64, GAS_HRTF_WAVES_PER_SIMD) void k_hrtf_ol
 		}
 		__syncthreads();
 		const float *red_all = reinterpret_cast<const float *>(lds_all);
-#pragma unroll
-		for (int r = 0; r < (int)(F * 2) / (WAVES * 64); r++) {
-			const int idx = threadIdx.x + r * WAVES * 64;
+		for (int idx = threadIdx.x; idx < (int)(F * 2); idx += WAVES * 64) {
 			float s = 0.0f;
 #pragma unroll
 			for (int w = 0; w < WAVES; w++) {
@@ -548,17 +549,28 @@ __global__ __launch_bounds__(WAVES * 64, GAS_HRTF_WAVES_PER_SIMD) void k_hrtf_ol
 			}
 		}
 		__syncthreads();
-#pragma unroll
-		for (int r = 0; r < (int)(F * 2) / (WAVES * 64); r++) {
-			const int idx = threadIdx.x + r * WAVES * 64;
+		for (int idx = threadIdx.x; idx < (int)(F * 2); idx += WAVES * 64) {
 			my_partial[idx] = outp[idx];
 		}
 	}
-	(void)p_stride;
 	(void)accL;
 	(void)accR;
 	(void)aYL;
 	(void)aYR;
+}
+
+// One launch per callback for every HRTF source: workgroups [0, wgs_fd) run the frequency-domain body over
+// g_fd, the rest run the exact-peak body over g_pk (the draining playbacks).
+template <int SQ, bool WITH_ER>
+__global__ __launch_bounds__(WAVES * 64, GAS_HRTF_WAVES_PER_SIMD) void k_hrtf_ols(gas_group_args g_fd, gas_group_args g_pk, uint32_t wgs_fd, gas_dev_state st, gas_hrtf_table tab, const float2 *__restrict__ tw, uint32_t spw_fd, uint32_t spw_pk, uint32_t er_R, float *__restrict__ partials, uint32_t p_offset) {
+	constexpr int LDS_F2 = HrtfLds<SQ, false>::TOTAL_F2 > HrtfLds<SQ, true>::TOTAL_F2 ? HrtfLds<SQ, false>::TOTAL_F2 : HrtfLds<SQ, true>::TOTAL_F2;
+	__shared__ float2 lds_all[LDS_F2];
+	float *my_partial = partials + ((size_t)p_offset + blockIdx.x) * (size_t)(2 * SQ * 64 * 2);
+	if (blockIdx.x < wgs_fd) {
+		hrtf_body<SQ, WITH_ER, false>(lds_all, blockIdx.x, g_fd, st, tab, tw, spw_fd, er_R, my_partial);
+	} else {
+		hrtf_body<SQ, WITH_ER, true>(lds_all, blockIdx.x - wgs_fd, g_pk, st, tab, tw, spw_pk, er_R, my_partial);
+	}
 }
 
 // HRIR [dirs][2][taps] -> lane-major half-spectra table (see issue_spectra), one wave per (direction, ear),
@@ -655,9 +667,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_er_only(gas_group_args g, gas_de
 	}
 	__syncthreads();
 	float *my_partial = partials + ((size_t)p_offset + blockIdx.x) * (F * 2);
-#pragma unroll
-	for (int r = 0; r < (int)(F * 2) / (WAVES * 64); r++) {
-		const int idx = threadIdx.x + r * WAVES * 64;
+	for (int idx = threadIdx.x; idx < (int)(F * 2); idx += WAVES * 64) {
 		float s = 0.0f;
 #pragma unroll
 		for (int w = 0; w < WAVES; w++) {
@@ -683,54 +693,65 @@ void gas_make_twiddles(float2 *host_tw) {
 	}
 }
 
-// Sources per wave: the kernel is resident at GAS_HRTF_WAVES_PER_SIMD waves/SIMD; hand every
-// resident wave the same number of sources so the grid drains in one even pass.  At most 64 per wave
-// (one metadata lane per source); beyond that the grid simply grows.
-uint32_t gas_hrtf_partials(uint32_t n, uint32_t *sources_per_wave) {
-	const uint32_t resident_waves = 256u * 4u * GAS_HRTF_WAVES_PER_SIMD;
-	uint32_t spw = (n + resident_waves - 1) / resident_waves;
-	if (spw < 1) {
-		spw = 1;
-	}
-	if (const char *ov = getenv("GAS_HRTF_SPW")) { // tuning aid
-		const int v = atoi(ov);
-		if (v > 0) {
-			spw = (uint32_t)v;
+// Launch plan of one k_hrtf_ols launch.  The kernel is resident at GAS_HRTF_WAVES_PER_SIMD waves/SIMD, i.e.
+// 256 * 4 * that / WAVES workgroups at a time; the frequency-domain and exact-peak workgroups share that
+// budget (an exact-peak source costs about twice a frequency-domain one) so the whole grid drains in one
+// even round.  At most 64 sources per wave (one metadata lane per source); beyond that the grid grows.
+void gas_hrtf_plan(uint32_t n_fd, uint32_t n_pk, gas_hrtf_launch_plan *p) {
+	const uint32_t budget = 256u * 4u * GAS_HRTF_WAVES_PER_SIMD / WAVES;
+	auto spw_for = [](uint32_t n, uint32_t wgs) {
+		uint32_t spw = (n + wgs * WAVES - 1) / (wgs * WAVES);
+		if (const char *ov = getenv("GAS_HRTF_SPW")) { // tuning aid
+			const int v = atoi(ov);
+			if (v > 0) {
+				spw = (uint32_t)v;
+			}
 		}
+		return spw < 1 ? 1u : (spw > 64 ? 64u : spw);
+	};
+	p->spw_fd = p->spw_pk = 1;
+	p->wgs_fd = p->wgs_pk = 0;
+	uint32_t budget_fd = budget;
+	if (n_pk) {
+		uint32_t share = n_fd ? (uint32_t)(((uint64_t)budget * 2 * n_pk + (n_fd + 2ull * n_pk) - 1) / (n_fd + 2ull * n_pk)) : budget;
+		share = share < 1 ? 1 : (share > budget - (n_fd ? 1 : 0) ? budget - (n_fd ? 1 : 0) : share);
+		p->spw_pk = spw_for(n_pk, share);
+		p->wgs_pk = (n_pk + p->spw_pk * WAVES - 1) / (p->spw_pk * WAVES);
+		budget_fd = budget > p->wgs_pk ? budget - p->wgs_pk : 1;
 	}
-	if (spw > 64) {
-		spw = 64;
+	if (n_fd) {
+		p->spw_fd = spw_for(n_fd, budget_fd);
+		p->wgs_fd = (n_fd + p->spw_fd * WAVES - 1) / (p->spw_fd * WAVES);
 	}
-	if (sources_per_wave) {
-		*sources_per_wave = spw;
-	}
-	const uint32_t per_wg = spw * WAVES;
-	return (n + per_wg - 1) / per_wg;
 }
 
-hipError_t gas_launch_hrtf_ols(hipStream_t stream, bool with_er, bool peaks, const gas_group_args &g, const gas_dev_state &st, const gas_hrtf_table &tab, const float2 *twiddles, uint32_t frames, uint32_t hist_len, uint32_t er_ring_frames, float *partials, uint32_t p_offset, uint32_t p_stride) {
-	if (g.n == 0) {
+uint32_t gas_hrtf_partials(uint32_t n, uint32_t *sources_per_wave) {
+	gas_hrtf_launch_plan p;
+	gas_hrtf_plan(n, 0, &p);
+	if (sources_per_wave) {
+		*sources_per_wave = p.spw_fd;
+	}
+	return p.wgs_fd;
+}
+
+hipError_t gas_launch_hrtf_ols(hipStream_t stream, bool with_er, const gas_group_args &g_fd, const gas_group_args &g_pk, const gas_dev_state &st, const gas_hrtf_table &tab, const float2 *twiddles, uint32_t frames, uint32_t hist_len, uint32_t er_ring_frames, float *partials, uint32_t p_offset) {
+	if (g_fd.n + g_pk.n == 0) {
 		return hipSuccess;
 	}
 	if (frames % 128 != 0 || frames > 512 || hist_len != 512 - frames / 2) {
 		return hipErrorInvalidValue;
 	}
-	uint32_t spw = 1;
-	const uint32_t wgs = gas_hrtf_partials(g.n, &spw);
-	dim3 grid(wgs), block(WAVES * 64);
-#define GAS_HRTF_LAUNCH(SQv, ERv, PKv) \
-	hipLaunchKernelGGL((k_hrtf_ols<SQv, ERv, PKv>), grid, block, 0, stream, g, st, tab, twiddles, spw, er_ring_frames, partials, p_offset, p_stride)
-#define GAS_HRTF_CASE(SQv)                        \
-	case SQv:                                     \
-		if (with_er && peaks) {                   \
-			GAS_HRTF_LAUNCH(SQv, true, true);     \
-		} else if (with_er) {                     \
-			GAS_HRTF_LAUNCH(SQv, true, false);    \
-		} else if (peaks) {                       \
-			GAS_HRTF_LAUNCH(SQv, false, true);    \
-		} else {                                  \
-			GAS_HRTF_LAUNCH(SQv, false, false);   \
-		}                                         \
+	gas_hrtf_launch_plan plan;
+	gas_hrtf_plan(g_fd.n, g_pk.n, &plan);
+	const uint32_t wgs_fd = plan.wgs_fd, spw_fd = plan.spw_fd, spw_pk = plan.spw_pk;
+	dim3 grid(plan.wgs_fd + plan.wgs_pk), block(WAVES * 64);
+#define GAS_HRTF_CASE(SQv)                                                                                                                                    \
+	case SQv:                                                                                                                                                 \
+		if (with_er) {                                                                                                                                        \
+			hipLaunchKernelGGL((k_hrtf_ols<SQv, true>), grid, block, 0, stream, g_fd, g_pk, wgs_fd, st, tab, twiddles, spw_fd, spw_pk, er_ring_frames, partials, p_offset);  \
+		} else {                                                                                                                                              \
+			hipLaunchKernelGGL((k_hrtf_ols<SQv, false>), grid, block, 0, stream, g_fd, g_pk, wgs_fd, st, tab, twiddles, spw_fd, spw_pk, er_ring_frames, partials, p_offset); \
+		}                                                                                                                                                     \
 		break;
 	switch (frames / 128) {
 		GAS_HRTF_CASE(1)
@@ -741,7 +762,6 @@ hipError_t gas_launch_hrtf_ols(hipStream_t stream, bool with_er, bool peaks, con
 			return hipErrorInvalidValue;
 	}
 #undef GAS_HRTF_CASE
-#undef GAS_HRTF_LAUNCH
 	return hipGetLastError();
 }
 

@@ -85,7 +85,15 @@ __global__ void k_zero_slot(gas_dev_state st, uint32_t slot, uint32_t hist_len, 
 	}
 }
 
+__global__ void k_noop() {
+}
+
 } // namespace
+
+hipError_t gas_launch_noop(hipStream_t stream) {
+	hipLaunchKernelGGL(k_noop, dim3(1), dim3(64), 0, stream);
+	return hipGetLastError();
+}
 
 hipError_t gas_launch_mix_reduce(hipStream_t stream, const float *partials, uint32_t p_count, uint32_t p_stride, uint32_t channels, uint32_t frames, gas_audio_frame *out) {
 	const uint32_t elems = frames * 2;

@@ -171,6 +171,7 @@ int gas_process_frames_1(gas_ctx *ctx, uint32_t slot, gas_audio_frame *out, cons
 int gas_mix_channel_1(gas_ctx *ctx, uint32_t slot, int channel, gas_audio_frame *out, const gas_audio_frame *src, int frame_count);
 
 /* ---- measurement ------------------------------------------------------- */
+/* on = 0 off, 1 = bracket the dominant launch of every callback with HIP events, N > 1 = of every Nth callback. */
 int gas_profile_enable(gas_ctx *ctx, int on);
 int gas_profile_read(gas_ctx *ctx, gas_profile *out, int reset);
 
