@@ -88,6 +88,7 @@ EXPORTS = [
     "gas_ctx_destroy",
     "gas_ctx_set_stream",
     "gas_ctx_synchronize",
+    "gas_ctx_get_config",
     "gas_strerror",
     "gas_last_device_error",
     "gas_source_alloc",
@@ -146,6 +147,7 @@ def load_library():
     L.gas_ctx_destroy.restype = None
     L.gas_ctx_set_stream.argtypes = [vp, vp]
     L.gas_ctx_synchronize.argtypes = [vp]
+    L.gas_ctx_get_config.argtypes = [vp, C.POINTER(Config)]
     L.gas_strerror.argtypes = [i32]
     L.gas_strerror.restype = C.c_char_p
     L.gas_last_device_error.argtypes = [vp]
@@ -298,3 +300,59 @@ class SpatializerContext:
         p = Profile()
         self._check(self.lib.gas_profile_read(self.h, C.byref(p), int(reset)), "gas_profile_read")
         return {"launches": p.launches, "kernel_ms": p.kernel_ms, "bytes_per_launch": p.bytes_per_launch, "kernel": p.kernel_name.decode()}
+
+
+class BatchedSpatializerHost:
+    """ctypes view of include/gas_amd_host.h: the CPU-side half of AudioSpatializerInstance
+    (source window, fade-out, latch, silence gate, list GC) over one gas_process_block per callback."""
+
+    def __init__(self, ctx, kind, effects=()):
+        self.ctx = ctx
+        L = self.lib = ctx.lib
+        vp, u32, i32 = C.c_void_p, C.c_uint32, C.c_int
+        L.gas_host_create.argtypes = [vp, i32, C.POINTER(C.c_int32), u32, C.POINTER(vp)]
+        L.gas_host_destroy.argtypes = [vp]
+        L.gas_host_destroy.restype = None
+        L.gas_host_start_playback_array.argtypes = [vp, vp, C.c_int64, C.POINTER(u32)]
+        L.gas_host_stop_playback.argtypes = [vp, u32]
+        L.gas_host_set_spatializer_parameters.argtypes = [vp, u32, vp]
+        L.gas_host_set_playback_disable_threshold_db.argtypes = [vp, C.c_float]
+        L.gas_host_set_playback_disable_threshold_db.restype = None
+        L.gas_host_is_playback_active.argtypes = [vp, u32]
+        L.gas_host_playback_count.argtypes = [vp]
+        L.gas_host_get_mixed_frames.argtypes = [vp, i32, vp, i32]
+        fx = (C.c_int32 * max(1, len(effects)))(*effects)
+        h = C.c_void_p()
+        ctx._check(L.gas_host_create(ctx.h, kind, fx, len(effects), C.byref(h)), "gas_host_create")
+        self.h = h
+        self._streams = []
+
+    def close(self):
+        if self.h:
+            self.lib.gas_host_destroy(self.h)
+            self.h = None
+
+    def start_playback_array(self, stream):
+        s = np.ascontiguousarray(stream, dtype=np.float32)
+        self._streams.append(s)  # the host reads it on every callback: keep it alive
+        pid = C.c_uint32()
+        self.ctx._check(self.lib.gas_host_start_playback_array(self.h, _np_ptr(s), s.shape[0], C.byref(pid)), "gas_host_start_playback_array")
+        return pid.value
+
+    def stop_playback(self, pid):
+        return self.lib.gas_host_stop_playback(self.h, pid)
+
+    def set_spatializer_parameters(self, pid, params):
+        p = np.ascontiguousarray(params, dtype=PARAMS_DTYPE).reshape(1)
+        self.ctx._check(self.lib.gas_host_set_spatializer_parameters(self.h, pid, _np_ptr(p)), "gas_host_set_spatializer_parameters")
+
+    def is_playback_active(self, pid):
+        return bool(self.lib.gas_host_is_playback_active(self.h, pid))
+
+    def playback_count(self):
+        return self.lib.gas_host_playback_count(self.h)
+
+    def get_mixed_frames(self, channel, frame_count):
+        out = np.full((frame_count, 2), np.nan, dtype=np.float32)
+        rc = self.lib.gas_host_get_mixed_frames(self.h, channel, _np_ptr(out), frame_count)
+        return rc, out

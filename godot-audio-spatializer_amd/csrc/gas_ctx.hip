@@ -607,6 +607,14 @@ int gas_ctx_set_stream(gas_ctx *c, void *hip_stream) {
 	return GAS_OK;
 }
 
+int gas_ctx_get_config(gas_ctx *c, gas_config *out) {
+	if (!c || !out) {
+		return GAS_ERR_INVALID_ARGUMENT;
+	}
+	*out = c->cfg;
+	return GAS_OK;
+}
+
 int gas_ctx_synchronize(gas_ctx *c) {
 	if (!c) {
 		return GAS_ERR_INVALID_ARGUMENT;

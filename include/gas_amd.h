@@ -134,6 +134,7 @@ void gas_ctx_destroy(gas_ctx *ctx);
 /* Run on an existing HIP stream (hipStream_t) instead of the context's own. */
 int gas_ctx_set_stream(gas_ctx *ctx, void *hip_stream);
 int gas_ctx_synchronize(gas_ctx *ctx);
+int gas_ctx_get_config(gas_ctx *ctx, gas_config *out); /* the configuration the context was created with */
 const char *gas_strerror(int status);
 const char *gas_last_device_error(gas_ctx *ctx);
 

@@ -1,0 +1,49 @@
+/*
+ * gas_amd_host.h -- engine-free C++ host layer over gas_amd.h, exported with a C surface.
+ *
+ * It restates the audio-thread half of AudioSpatializerInstance that stays on the CPU when the DSP moves
+ * to the GPU: the playback list (audio_spatializer.h:55-68), start/stop (audio_spatializer.cpp:44-113), the
+ * 64-frame source window with end-of-stream fade-out (:367-408), the once-per-callback latch (:494-508),
+ * get_mixed_frames (:510-527), the silence gate (:464-469) and the list GC (:473-492) -- but with ONE
+ * gas_process_block for all playbacks where the reference loops process_frames / mix_channel per playback.
+ * In a Godot build the same class sits behind AudioStreamPlaybackSpatial::mix; here the
+ * engine's AudioStreamPlayback::mix is a plain callback.
+ */
+#ifndef GAS_AMD_HOST_H
+#define GAS_AMD_HOST_H
+
+#include "gas_amd.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct gas_host gas_host;
+
+/* [ENGINE] AudioStreamPlayback::mix(AudioFrame *buffer, float rate_scale, int frames) -> frames mixed. */
+typedef int (*gas_host_stream_mix_fn)(void *user, gas_audio_frame *buffer, float rate_scale, int frames);
+
+/* One host = one AudioSpatializerInstance flavour (kind + effect chain) batching all its playbacks. */
+int gas_host_create(gas_ctx *ctx, int kind, const int32_t *effects, uint32_t n_effects, gas_host **out_host);
+void gas_host_destroy(gas_host *host);
+
+/* start_playback_stream (audio_spatializer.cpp:44-96): allocates the slot, zeroes the lookahead. */
+int gas_host_start_playback(gas_host *host, gas_host_stream_mix_fn mix, void *user, uint32_t *out_id);
+/* Convenience for tests/tools: a playback over a caller-owned array of frames (zero-filled past its end). */
+int gas_host_start_playback_array(gas_host *host, const gas_audio_frame *stream, int64_t stream_frames, uint32_t *out_id);
+/* stop_playback_stream (audio_spatializer.cpp:98-113): active = false; the audio thread reaps it. */
+int gas_host_stop_playback(gas_host *host, uint32_t id);
+/* set_spatializer_parameters (audio_spatializer.cpp:558-564), per playback. */
+int gas_host_set_spatializer_parameters(gas_host *host, uint32_t id, const gas_params *params);
+void gas_host_set_playback_disable_threshold_db(gas_host *host, float db); /* audio_spatializer.h:87 */
+int gas_host_is_playback_active(gas_host *host, uint32_t id);
+int gas_host_playback_count(gas_host *host); /* nodes still on the list */
+
+/* get_mixed_frames (audio_spatializer.cpp:510-527): audio thread; returns GAS_OK, GAS_ERR_BAD_CHANNEL
+ * ("Unexpected channel") or GAS_ERR_FRAME_COUNT ("Unexpected frame count"). */
+int gas_host_get_mixed_frames(gas_host *host, int channel, gas_audio_frame *frames, int frame_count);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
