@@ -810,7 +810,7 @@ int gas_process_block(gas_ctx *c, const gas_audio_frame *src, const uint32_t *sl
 		return fail(GAS_ERR_NO_DEVICE);
 	}
 	apply_pending_frees(c);
-	if (slots) {
+	if (slots || n == 0) { // an empty callback needs no list
 		rc = build_groups(c, slots, n);
 		if (rc != GAS_OK) {
 			c->cached_n = UINT32_MAX;

@@ -1,0 +1,235 @@
+"""Edge cases of the boundary on the GPU: the cases the reference guards with ERR_FAIL_* and the ones a batched
+mixer adds (empty callback, mixed kinds, slot reuse, latest-wins parameters, single-source entry points)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from helpers import TOL, mix_matches, rel_rms
+
+pytestmark = pytest.mark.gpu
+
+
+def hrir8():
+    from godot_audio_spatializer_amd import synth
+
+    return synth.synthetic_hrir(np.random.default_rng(7), dirs=8)
+
+
+def test_empty_callback_yields_silence(gas):
+    with gas.SpatializerContext(max_sources=4, frames=512, channel_count=2) as ctx:
+        mix, peaks = ctx.process_block(np.zeros((0, 512, 2), np.float32), np.zeros(0, np.uint32))
+        assert mix.shape == (2, 512, 2) and not mix.any()  # audio_spatializer.cpp:335-343
+
+
+def test_error_paths_return_codes_and_zero_the_mix(gas):
+    from godot_audio_spatializer_amd import synth
+
+    rng = np.random.default_rng(0)
+    with gas.SpatializerContext(max_sources=4, frames=512) as ctx:
+        lib, h = ctx.lib, ctx.h
+        s0 = ctx.source_alloc(gas.capi.KIND_3D_MIX)
+        src = synth.draw_sources(rng, 1, 512)
+        out = np.full((1, 512, 2), 7.0, np.float32)
+        pk = np.zeros((1, 2), np.float32)
+        slots = np.array([s0], np.uint32)
+
+        def call(src_, slots_, n, frames):
+            out[:] = 7.0
+            return lib.gas_process_block(h, src_.ctypes.data, slots_.ctypes.data, n, frames, out.ctypes.data, pk.ctypes.data, 0)
+
+        assert call(src, slots, 1, 512) == -12 and not out.any()  # no parameters yet (audio_spatializer.cpp:330)
+        ctx.params_publish(s0, synth.draw_params(rng, 1)[0])
+        assert call(src, slots, 1, 256) == -4 and not out.any()  # "Unexpected frame count" (:522)
+        assert call(src, np.array([3], np.uint32), 1, 512) == -3 and not out.any()  # slot never allocated
+        assert call(src, np.array([99], np.uint32), 1, 512) == -3
+        two = np.concatenate([src, src])
+        assert call(two, np.array([s0, s0], np.uint32), 2, 512) == -1  # one playback twice in a callback
+        assert call(src, slots, 1, 512) == 0 and out.any()
+        # HRTF before gas_hrtf_load
+        s1 = ctx.source_alloc(gas.capi.KIND_EFFECT, (gas.capi.FX_HRTF,))
+        ctx.params_publish(s1, synth.draw_params(rng, 1, dirs=8)[0])
+        assert call(src, np.array([s1], np.uint32), 1, 512) == -5 and not out.any()
+        # unsupported chains / kinds
+        fx = (C.c_int32 * 2)(gas.capi.FX_HRTF, gas.capi.FX_HIGHSHELF)
+        slot = C.c_uint32()
+        assert lib.gas_source_alloc(h, gas.capi.KIND_EFFECT, fx, 2, C.byref(slot)) == -6
+        assert lib.gas_source_alloc(h, 7, None, 0, C.byref(slot)) == -1
+        fx1 = (C.c_int32 * 1)(gas.capi.FX_EARLY_REFLECTIONS)
+        assert lib.gas_source_alloc(h, gas.capi.KIND_EFFECT, fx1, 1, C.byref(slot)) == -6  # context has no ER ring
+        # slot exhaustion
+        got = [ctx.source_alloc(gas.capi.KIND_3D_MIX) for _ in range(2)]
+        assert lib.gas_source_alloc(h, gas.capi.KIND_3D_MIX, None, 0, C.byref(slot)) == -2
+        assert lib.gas_source_free(h, 99) == -3
+        # single-source entry points: kind / channel checks
+        o1 = np.zeros((512, 2), np.float32)
+        assert lib.gas_mix_channel_1(h, s1, 0, o1.ctypes.data, src.ctypes.data, 512) == -10
+        assert lib.gas_mix_channel_1(h, s0, 4, o1.ctypes.data, src.ctypes.data, 512) == -11
+        assert lib.gas_process_frames_1(h, s0, o1.ctypes.data, src.ctypes.data, 100) == -4
+
+
+def test_freed_slot_is_reused_with_fresh_state(gas, ob):
+    from godot_audio_spatializer_amd import synth
+
+    rng = np.random.default_rng(1)
+    hr = hrir8()
+    with gas.SpatializerContext(max_sources=2, frames=512) as ctx:
+        ctx.hrtf_load(hr)
+        chain = (gas.capi.FX_HRTF,)
+        a = ctx.source_alloc(gas.capi.KIND_EFFECT, chain)
+        b = ctx.source_alloc(gas.capi.KIND_EFFECT, chain)
+        p = synth.draw_params(rng, 2, dirs=8)
+        ctx.params_publish_batch([a, b], p)
+        for _ in range(3):  # build up history
+            ctx.process_block(synth.draw_sources(rng, 2, 512), [a, b])
+        ctx.source_free(a)  # takes effect at the next block boundary
+        ctx.process_block(synth.draw_sources(rng, 1, 512), [b])
+        a2 = ctx.source_alloc(gas.capi.KIND_EFFECT, chain)
+        assert a2 == a
+        ctx.params_publish(a2, p[0])
+        src = synth.draw_sources(rng, 1, 512)
+        mix, peaks = ctx.process_block(src, [a2])
+        fresh = ob.BatchOracle(ob.KIND_EFFECT, 1, 512, chain=[ob.FX_HRTF], hrir=hr)
+        _, rp, r64 = fresh.block(p[:1].astype(ob.PARAMS_DTYPE), src, want64=True)
+        assert rel_rms(mix[0], r64[0]) <= TOL  # no trace of the previous playback's history / gain
+        # gas_source_reset does the same for a live slot
+        ctx.process_block(synth.draw_sources(rng, 1, 512), [a2])
+        ctx.source_reset(a2)
+        mix2, _ = ctx.process_block(src, [a2])
+        assert rel_rms(mix2[0], r64[0]) <= TOL
+
+
+def test_mixed_kinds_in_one_callback(gas, ob):
+    """3D mix_channel (2 pairs), 3D process_frames, empty chain, high-shelf chain, HRTF and ER+HRTF playbacks in
+    the same callback, interleaved row order: out = sum of what each instance flavour would have mixed."""
+    from godot_audio_spatializer_amd import synth
+
+    rng = np.random.default_rng(2)
+    hr = hrir8()
+    F, per = 256, 9
+    K = gas.capi
+    flavours = [(K.KIND_3D_MIX, ()), (K.KIND_3D_PROCESS, ()), (K.KIND_EFFECT, ()), (K.KIND_EFFECT, (K.FX_HIGHSHELF,)), (K.KIND_EFFECT, (K.FX_HRTF,)), (K.KIND_EFFECT, (K.FX_EARLY_REFLECTIONS, K.FX_HRTF)), (K.KIND_EFFECT, (K.FX_EARLY_REFLECTIONS,))]
+    with gas.SpatializerContext(max_sources=per * len(flavours), frames=F, channel_count=2, er_ring_frames=4096, flags=K.FLAG_PEAKS_DRAINING_ONLY) as ctx:
+        ctx.hrtf_load(hr)
+        slots, kinds = [], []
+        for i in range(per):  # interleave flavours across rows
+            for f, (kind, chain) in enumerate(flavours):
+                slots.append(ctx.source_alloc(kind, chain))
+                kinds.append(f)
+        slots, kinds = np.array(slots, np.uint32), np.array(kinds)
+        ctx.source_set_draining(slots[4], True)  # one HRTF playback keeps exact peaks
+        oras = [ob.BatchOracle(kind, per, F, channel_count=2, chain=chain, hrir=hr, er_ring_frames=4096) for kind, chain in flavours]
+        n = len(slots)
+        for b in range(5):
+            if b % 2 == 0:
+                p = synth.draw_params(rng, n, dirs=8, channel_count=2, ring_frames=4096, frames=F)
+                ctx.params_publish_batch(slots, p)
+            src = synth.draw_sources(rng, n, F)
+            mix, peaks = ctx.process_block(src, slots)
+            want = np.zeros((2, F, 2))
+            for f, ora in enumerate(oras):
+                sel = kinds == f
+                m, pk, m64 = ora.block(p[sel].astype(ob.PARAMS_DTYPE), src[sel], want64=True)
+                want[: m64.shape[0]] += m64
+                if flavours[f][1] and flavours[f][1][-1] == K.FX_HRTF:
+                    got = peaks[sel]
+                    exact = np.isfinite(got[:, 0])
+                    assert exact.sum() == (1 if f == 4 else 0)
+                    np.testing.assert_allclose(got[exact], pk[exact], rtol=2e-5, atol=1e-7)
+                else:
+                    np.testing.assert_allclose(peaks[sel], pk, rtol=2e-5, atol=1e-7)
+            for c in range(2):
+                assert rel_rms(mix[c], want[c]) <= TOL, f"block {b} channel {c}"
+
+
+def test_latest_published_parameters_win(gas, ob):
+    from godot_audio_spatializer_amd import synth
+
+    rng = np.random.default_rng(3)
+    with gas.SpatializerContext(max_sources=3, frames=512) as ctx:
+        slots = ctx.source_alloc_many(3, gas.capi.KIND_3D_MIX)
+        p_old, p_new = synth.draw_params(rng, 3), synth.draw_params(rng, 3)
+        ctx.params_publish_batch(slots, p_old)
+        for s, p in zip(slots, p_new):  # several publishes between two callbacks: the last one is used
+            ctx.params_publish(s, p_old[0])
+            ctx.params_publish(s, p)
+        src = synth.draw_sources(rng, 3, 512)
+        mix, _ = ctx.process_block(src, slots)
+        ora = ob.BatchOracle(ob.KIND_3D_MIX, 3, 512)
+        _, _, r64 = ora.block(p_new.astype(ob.PARAMS_DTYPE), src, want64=True)
+        assert rel_rms(mix[0], r64[0]) <= TOL
+
+
+@pytest.mark.parametrize("mode", ["process_frames", "mix_channel", "effect_hrtf"])
+def test_single_source_entry_points(gas, ob, mode):
+    """gas_process_frames_1 / gas_mix_channel_1 against the oracle's process_frames / mix_channel, call by call."""
+    from godot_audio_spatializer_amd import synth
+
+    rng = np.random.default_rng(4)
+    F = 512
+    hr = hrir8()
+    L = ob.lib()
+    with gas.SpatializerContext(max_sources=2, frames=F, channel_count=4) as ctx:
+        ctx.hrtf_load(hr)
+        if mode == "effect_hrtf":
+            slot = ctx.source_alloc(gas.capi.KIND_EFFECT, (gas.capi.FX_HRTF,))
+            ora = ob.BatchOracle(ob.KIND_EFFECT, 1, F, chain=[ob.FX_HRTF], hrir=hr)
+        else:
+            slot = ctx.source_alloc(gas.capi.KIND_3D_MIX)
+        pd = ob.PData3D()
+        for b in range(4):
+            p = synth.draw_params(rng, 1, dirs=8, channel_count=4)
+            ctx.params_publish(slot, p[0])
+            po = p.astype(ob.PARAMS_DTYPE)
+            pp = po.ctypes.data_as(C.POINTER(ob.Params))
+            src = synth.draw_sources(rng, 1, F)[0]
+            want = np.zeros((F, 2), np.float32)
+            if mode == "process_frames":
+                got = ctx.process_frames_1(slot, src)
+                L.gaso_process_frames_3d(pp, C.byref(pd), want.ctypes.data, src.ctypes.data, F, 48000.0)
+                assert mix_matches(got, want)
+            elif mode == "mix_channel":
+                for ch in (0, 2, 3):  # audio_spatializer.cpp:424-430 calls it per channel on the same source
+                    got = ctx.mix_channel_1(slot, ch, src)
+                    L.gaso_mix_channel_3d(pp, C.byref(pd), ch, want.ctypes.data, src.ctypes.data, F, 48000.0)
+                    assert mix_matches(got, want), (b, ch)
+            else:
+                got = ctx.process_frames_1(slot, src)
+                _, _, r64 = ora.block(po, src[None], want64=True)
+                assert mix_matches(got, r64[0])
+
+
+def test_device_memory_path_equals_host_memory_path(gas):
+    import torch
+
+    from godot_audio_spatializer_amd import synth
+
+    rng = np.random.default_rng(5)
+    n, F = 70, 512
+    hr = hrir8()
+    res = []
+    for mem in ("host", "device"):
+        rng = np.random.default_rng(5)
+        with gas.SpatializerContext(max_sources=n, frames=F) as ctx:
+            ctx.hrtf_load(hr)
+            slots = ctx.source_alloc_many(n, gas.capi.KIND_EFFECT, (gas.capi.FX_HRTF,))
+            outs = []
+            for b in range(3):
+                ctx.params_publish_batch(slots, synth.draw_params(rng, n, dirs=8))
+                src = synth.draw_sources(rng, n, F)
+                if mem == "host":
+                    mix, peaks = ctx.process_block(src, slots)
+                else:
+                    d_src = torch.from_numpy(src).cuda()
+                    d_out = torch.zeros(1, F, 2, device="cuda")
+                    d_pk = torch.zeros(n, 2, device="cuda")
+                    torch.cuda.synchronize()
+                    rc = ctx.process_block_raw(d_src.data_ptr(), slots if b == 0 else None, n, F, d_out.data_ptr(), d_pk.data_ptr(), gas.capi.MEM_DEVICE)
+                    assert rc == 0
+                    ctx.synchronize()
+                    mix, peaks = d_out.cpu().numpy(), d_pk.cpu().numpy()
+                outs.append((mix.copy(), peaks.copy()))
+            res.append(outs)
+    for (m0, p0), (m1, p1) in zip(*res):
+        np.testing.assert_array_equal(m0, m1)  # same kernels, same order: bitwise
+        np.testing.assert_array_equal(p0, p1)
