@@ -34,6 +34,22 @@ HBM_PEAK = 8.0e12  # MI355X_MICROARCH.md: 8 TB/s spec
 N_SRC_BUFFERS_BYTES = 320 << 20  # rotate source buffers over > 256 MiB so the Infinity Cache cannot hold them
 
 
+def pmc_traffic(kernel, workload, n_local, peaks):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes of this same command (profiles/*_pmc.json,
+    written by tools/profile_bench.sh; FETCH_SIZE x2 + WRITE_SIZE), or None."""
+    import glob
+
+    best = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json"))):
+        try:
+            rec = json.load(open(path))
+        except (OSError, ValueError):
+            continue
+        if rec.get("kernel") == kernel and rec.get("workload") == workload and rec.get("sources_per_gpu") == n_local and rec.get("peaks") == peaks:
+            best = (rec["traffic_bytes_per_launch"], os.path.basename(path))
+    return best
+
+
 def cpu_baseline(kind, chain, frames, dirs, hrir, ring, budget_s=12.0):
     """Reference-equivalent CPU path (oracle, scalar f32, 1 core) on a bounded sample of the workload."""
     from oracle import binding as ob
@@ -230,12 +246,19 @@ def main():
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK,
                 "traffic": None,
+                "traffic_source": None,
                 "kernel": prof["kernel"],
                 "kernel_us": k_ms * 1e3,
                 "launches_timed": prof["launches"],
                 "algorithmic_bytes_per_launch": prof["bytes_per_launch"],
             },
         }
+
+    if rank == 0:
+        t = pmc_traffic(result["roofline"]["kernel"], desc, n_local, result["config"].get("peaks"))
+        if t:
+            result["roofline"]["traffic"] = t[0] / 1e9 * 1e9  # bytes per launch
+            result["roofline"]["traffic_source"] = "profiles/" + t[1] + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command; FETCH x2 on gfx950)"
 
     # ---- extras on one GPU: max concurrent sources inside the 10.67 ms callback, CPU baseline ----
     del srcs

@@ -62,6 +62,135 @@ __device__ inline Coeffs highshelf_coeffs(float sampling_rate, float cutoff_hz, 
 	return c;
 }
 
+// Per-lane recurrence state.
+struct LaneState {
+	Coeffs co, inc;
+	float ha1, ha2, hb1, hb2;
+	float vs, vf;
+	float peak;
+	bool filt, valid;
+};
+
+// The tile loop, specialised on the two wave-uniform conditions so neither the IEEE division of the
+// non-power-of-two lerp nor the bypass-branch selects are evaluated per step.
+template <int MODE, bool F_POW2, bool ALL_FILT>
+__device__ __forceinline__ void run_tiles(LaneState &L, float (&tile)[2][SRC_PER_WG * ROW], const float *const (&ld_base)[4], uint32_t F, float *__restrict__ my_partial, int lane, int sl, int ear) {
+	Coeffs co = L.co, inc = L.inc;
+	float ha1 = L.ha1, ha2 = L.ha2, hb1 = L.hb1, hb2 = L.hb2;
+	const float vs = L.vs, vf = L.vf;
+	const bool filt = L.filt, valid = L.valid;
+	float peak = 0.0f;
+	constexpr bool f_pow2 = F_POW2;
+	constexpr bool all_filt = ALL_FILT;
+	const float Ff = (float)(int)F;
+	const float invF = 1.0f / Ff;
+	const uint32_t n_tiles = F / KF;
+	float4 pre[4];
+#pragma unroll
+	for (int q = 0; q < 4; q++) {
+		pre[q] = *reinterpret_cast<const float4 *>(ld_base[q]);
+	}
+
+	for (uint32_t tl = 0; tl < n_tiles; tl++) {
+		float *tb = tile[tl & 1];
+		// registers -> LDS (two 8-byte stores; rows are 136 B so 16-byte stores would misalign)
+#pragma unroll
+		for (int q = 0; q < 4; q++) {
+			int idx = q * 64 + lane;
+			float *d = tb + (idx >> 3) * ROW + (idx & 7) * 4;
+			*reinterpret_cast<float2 *>(d) = make_float2(pre[q].x, pre[q].y);
+			*reinterpret_cast<float2 *>(d + 2) = make_float2(pre[q].z, pre[q].w);
+		}
+		if (tl + 1 < n_tiles) {
+#pragma unroll
+			for (int q = 0; q < 4; q++) {
+				pre[q] = *reinterpret_cast<const float4 *>(ld_base[q] + (size_t)(tl + 1) * KF * 2);
+			}
+		}
+		__syncthreads();
+
+		float *mine = tb + sl * ROW + ear;
+		const int i0 = (int)(tl * KF);
+		// the tile's 16 samples of this stream into registers first: no LDS latency inside the recurrence
+		float xr[KF];
+#pragma unroll
+		for (int k = 0; k < KF; k++) {
+			xr[k] = mine[2 * k];
+		}
+#pragma unroll
+		for (int k = 0; k < KF; k++) {
+			float x = xr[k];
+			float y;
+			if constexpr (MODE == GAS_MODE_MIX_CHANNEL) {
+				const float fi = (float)(i0 + k);
+				const float t = f_pow2 ? fi * invF : fi / Ff; // (float)frame_idx / p_frame_count (:591)
+				const float vol = vf * t + (1 - t) * vs; // :592
+				x = vol * x; // :593
+			}
+			if constexpr (MODE == GAS_MODE_COPY) {
+				y = x;
+			} else {
+				// [ENGINE] process_one(_interp)
+				const float yf = x * co.b0 + hb1 * co.b1 + hb2 * co.b2 + ha1 * co.a1 + ha2 * co.a2;
+				if (all_filt) {
+					y = yf;
+					ha2 = ha1;
+					hb2 = hb1;
+					hb1 = x;
+					ha1 = yf;
+				} else {
+					// bypass branch (:530-535, :599-605) leaves the processor untouched
+					y = filt ? yf : x;
+					ha2 = filt ? ha1 : ha2;
+					hb2 = filt ? hb1 : hb2;
+					hb1 = filt ? x : hb1;
+					ha1 = filt ? yf : ha1;
+				}
+				if constexpr (MODE != GAS_MODE_FX_HIGHSHELF) {
+					co.b0 += inc.b0;
+					co.b1 += inc.b1;
+					co.b2 += inc.b2;
+					co.a1 += inc.a1;
+					co.a2 += inc.a2;
+				}
+			}
+			y = valid ? y : 0.0f;
+			const float a = fabsf(y);
+			peak = a > peak ? a : peak; // :436-443
+			xr[k] = y;
+		}
+#pragma unroll
+		for (int k = 0; k < KF; k++) {
+			mine[2 * k] = xr[k];
+		}
+		__syncthreads();
+
+		// role switch: lane (h, j) sums column j = frame*2+ear over sources 16h .. 16h+15, in order
+		{
+			const int h = lane >> 5, j = lane & 31;
+			const float *col = tb + (16 * h) * ROW + j;
+			float s = 0.0f;
+#pragma unroll
+			for (int k = 0; k < 16; k++) {
+				s += col[k * ROW];
+			}
+			const float s_hi = __shfl_down(s, 32);
+			if (lane < 32) {
+				my_partial[(size_t)tl * (KF * 2) + j] = s + s_hi;
+			}
+		}
+		// the next iteration writes the other buffer; this one is rewritten two tiles later,
+		// after the __syncthreads() that follows that write.
+	}
+
+	L.co = co;
+	L.ha1 = ha1;
+	L.ha2 = ha2;
+	L.hb1 = hb1;
+	L.hb2 = hb2;
+	L.peak = peak;
+}
+
 template <int MODE>
 __global__ __launch_bounds__(64) void k_biquad_mix(gas_group_args g, gas_dev_state st, uint32_t F, uint32_t c0, float mix_rate, float *__restrict__ partials, uint32_t p_offset, uint32_t p_stride) {
 	__shared__ float tile[2][SRC_PER_WG * ROW];
@@ -154,100 +283,27 @@ __global__ __launch_bounds__(64) void k_biquad_mix(gas_group_args g, gas_dev_sta
 
 	const bool all_filt = __all(filt || !valid);
 	const bool f_pow2 = (F & (F - 1)) == 0;
-	const float Ff = (float)(int)F;
-	const float invF = 1.0f / Ff;
-	float peak = 0.0f;
-
-	const uint32_t n_tiles = F / KF;
-	float4 pre[4];
-#pragma unroll
-	for (int q = 0; q < 4; q++) {
-		pre[q] = *reinterpret_cast<const float4 *>(ld_base[q]);
-	}
-
 	float *my_partial = partials + ((size_t)blockIdx.y * p_stride + p_offset + blockIdx.x) * (size_t)F * 2;
-
-	for (uint32_t tl = 0; tl < n_tiles; tl++) {
-		float *tb = tile[tl & 1];
-		// registers -> LDS (two 8-byte stores; rows are 136 B so 16-byte stores would misalign)
-#pragma unroll
-		for (int q = 0; q < 4; q++) {
-			int idx = q * 64 + lane;
-			float *d = tb + (idx >> 3) * ROW + (idx & 7) * 4;
-			*reinterpret_cast<float2 *>(d) = make_float2(pre[q].x, pre[q].y);
-			*reinterpret_cast<float2 *>(d + 2) = make_float2(pre[q].z, pre[q].w);
+	LaneState L{ co, inc, ha1, ha2, hb1, hb2, vs, vf, 0.0f, filt, valid };
+	if (f_pow2) {
+		if (all_filt) {
+			run_tiles<MODE, true, true>(L, tile, ld_base, F, my_partial, lane, sl, ear);
+		} else {
+			run_tiles<MODE, true, false>(L, tile, ld_base, F, my_partial, lane, sl, ear);
 		}
-		if (tl + 1 < n_tiles) {
-#pragma unroll
-			for (int q = 0; q < 4; q++) {
-				pre[q] = *reinterpret_cast<const float4 *>(ld_base[q] + (size_t)(tl + 1) * KF * 2);
-			}
+	} else {
+		if (all_filt) {
+			run_tiles<MODE, false, true>(L, tile, ld_base, F, my_partial, lane, sl, ear);
+		} else {
+			run_tiles<MODE, false, false>(L, tile, ld_base, F, my_partial, lane, sl, ear);
 		}
-		__syncthreads();
-
-		float *mine = tb + sl * ROW + ear;
-		const int i0 = (int)(tl * KF);
-#pragma unroll 4
-		for (int k = 0; k < KF; k++) {
-			float x = mine[2 * k];
-			float y;
-			if constexpr (MODE == GAS_MODE_MIX_CHANNEL) {
-				const float fi = (float)(i0 + k);
-				const float t = f_pow2 ? fi * invF : fi / Ff; // (float)frame_idx / p_frame_count (:591)
-				const float vol = vf * t + (1 - t) * vs; // :592
-				x = vol * x; // :593
-			}
-			if constexpr (MODE == GAS_MODE_COPY) {
-				y = x;
-			} else {
-				// [ENGINE] process_one(_interp)
-				const float yf = x * co.b0 + hb1 * co.b1 + hb2 * co.b2 + ha1 * co.a1 + ha2 * co.a2;
-				if (all_filt) {
-					y = yf;
-					ha2 = ha1;
-					hb2 = hb1;
-					hb1 = x;
-					ha1 = yf;
-				} else {
-					// bypass branch (:530-535, :599-605) leaves the processor untouched
-					y = filt ? yf : x;
-					ha2 = filt ? ha1 : ha2;
-					hb2 = filt ? hb1 : hb2;
-					hb1 = filt ? x : hb1;
-					ha1 = filt ? yf : ha1;
-				}
-				if constexpr (MODE != GAS_MODE_FX_HIGHSHELF) {
-					co.b0 += inc.b0;
-					co.b1 += inc.b1;
-					co.b2 += inc.b2;
-					co.a1 += inc.a1;
-					co.a2 += inc.a2;
-				}
-			}
-			y = valid ? y : 0.0f;
-			const float a = fabsf(y);
-			peak = a > peak ? a : peak; // :436-443
-			mine[2 * k] = y;
-		}
-		__syncthreads();
-
-		// role switch: lane (h, j) sums column j = frame*2+ear over sources 16h .. 16h+15, in order
-		{
-			const int h = lane >> 5, j = lane & 31;
-			const float *col = tb + (16 * h) * ROW + j;
-			float s = 0.0f;
-#pragma unroll
-			for (int k = 0; k < 16; k++) {
-				s += col[k * ROW];
-			}
-			const float s_hi = __shfl_down(s, 32);
-			if (lane < 32) {
-				my_partial[(size_t)tl * (KF * 2) + j] = s + s_hi;
-			}
-		}
-		// the next iteration writes the other buffer; this one is rewritten two tiles later,
-		// after the __syncthreads() that follows that write.
 	}
+	co = L.co;
+	ha1 = L.ha1;
+	ha2 = L.ha2;
+	hb1 = L.hb1;
+	hb2 = L.hb2;
+	const float peak = L.peak;
 
 	if (valid) {
 		if constexpr (MODE != GAS_MODE_COPY) {

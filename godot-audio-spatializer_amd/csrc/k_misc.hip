@@ -9,45 +9,48 @@
 
 namespace {
 
-constexpr int RED_GROUPS = 16; // partial groups summed in parallel per output element
-constexpr int RED_OUT = 16; // output elements per workgroup (256 threads = 16 x 16)
+constexpr int RED_ROWS = 64; // partial rows summed in parallel per output column
+constexpr int RED_COLS = 4; // float4 columns (16 output floats) per workgroup; 256 threads = 64 x 4
 
-// out[c][i] = sum_p partials[c][p][i]; thread (o, gidx) sums partials gidx, gidx+16, ... in order,
-// then the 16 group sums are added in fixed order by gidx 0.  Bitwise reproducible.
-__global__ __launch_bounds__(256) void k_mix_reduce(const float *__restrict__ partials, uint32_t p_count, uint32_t p_stride, uint32_t elems /* F*2 */, float *__restrict__ out) {
-	__shared__ float red[RED_GROUPS][RED_OUT + 1];
-	const int o = threadIdx.x & (RED_OUT - 1);
-	const int gidx = threadIdx.x / RED_OUT;
-	const uint32_t i = blockIdx.x * RED_OUT + o;
+// out[c][i] = sum_p partials[c][p][i].  Thread (prow, col) adds partial rows prow, prow+64, ... of its float4
+// column (four independent 16-byte loads in flight per trip), then the 64 row sums are added in fixed order.
+// Bitwise reproducible; no atomics.
+__global__ __launch_bounds__(256) void k_mix_reduce(const float *__restrict__ partials, uint32_t p_count, uint32_t p_stride, uint32_t elems /* F*2, multiple of 4 */, float *__restrict__ out) {
+	__shared__ float4 red[RED_ROWS][RED_COLS];
+	const int col = threadIdx.x & (RED_COLS - 1);
+	const int prow = threadIdx.x / RED_COLS;
+	const uint32_t i4 = blockIdx.x * RED_COLS + col; // float4 index within a partial
 	const uint32_t c = blockIdx.y;
-	float s = 0.0f;
-	if (i < elems) {
-		const float *p = partials + (size_t)c * p_stride * elems + i;
-		uint32_t k = gidx;
-		// 4 independent loads in flight per trip
-		for (; k + 3 * RED_GROUPS < p_count; k += 4 * RED_GROUPS) {
-			float a0 = p[(size_t)k * elems];
-			float a1 = p[(size_t)(k + RED_GROUPS) * elems];
-			float a2 = p[(size_t)(k + 2 * RED_GROUPS) * elems];
-			float a3 = p[(size_t)(k + 3 * RED_GROUPS) * elems];
-			s += a0;
-			s += a1;
-			s += a2;
-			s += a3;
+	const uint32_t e4 = elems / 4;
+	float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+	if (i4 < e4) {
+		const float4 *p = reinterpret_cast<const float4 *>(partials + (size_t)c * p_stride * elems) + i4;
+		uint32_t k = prow;
+		for (; k + 3 * RED_ROWS < p_count; k += 4 * RED_ROWS) {
+			const float4 a0 = p[(size_t)k * e4];
+			const float4 a1 = p[(size_t)(k + RED_ROWS) * e4];
+			const float4 a2 = p[(size_t)(k + 2 * RED_ROWS) * e4];
+			const float4 a3 = p[(size_t)(k + 3 * RED_ROWS) * e4];
+			s.x += a0.x; s.y += a0.y; s.z += a0.z; s.w += a0.w;
+			s.x += a1.x; s.y += a1.y; s.z += a1.z; s.w += a1.w;
+			s.x += a2.x; s.y += a2.y; s.z += a2.z; s.w += a2.w;
+			s.x += a3.x; s.y += a3.y; s.z += a3.z; s.w += a3.w;
 		}
-		for (; k < p_count; k += RED_GROUPS) {
-			s += p[(size_t)k * elems];
+		for (; k < p_count; k += RED_ROWS) {
+			const float4 a = p[(size_t)k * e4];
+			s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
 		}
 	}
-	red[gidx][o] = s;
+	red[prow][col] = s;
 	__syncthreads();
-	if (gidx == 0 && i < elems) {
-		float t = 0.0f;
-#pragma unroll
-		for (int q = 0; q < RED_GROUPS; q++) {
-			t += red[q][o];
+	if (prow == 0 && i4 < e4) {
+		float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 8
+		for (int q = 0; q < RED_ROWS; q++) {
+			const float4 a = red[q][col];
+			t.x += a.x; t.y += a.y; t.z += a.z; t.w += a.w;
 		}
-		out[(size_t)c * elems + i] = t;
+		reinterpret_cast<float4 *>(out + (size_t)c * elems)[i4] = t;
 	}
 }
 
@@ -97,7 +100,7 @@ hipError_t gas_launch_noop(hipStream_t stream) {
 
 hipError_t gas_launch_mix_reduce(hipStream_t stream, const float *partials, uint32_t p_count, uint32_t p_stride, uint32_t channels, uint32_t frames, gas_audio_frame *out) {
 	const uint32_t elems = frames * 2;
-	dim3 grid((elems + RED_OUT - 1) / RED_OUT, channels);
+	dim3 grid((elems / 4 + RED_COLS - 1) / RED_COLS, channels);
 	hipLaunchKernelGGL(k_mix_reduce, grid, dim3(256), 0, stream, partials, p_count, p_stride, elems, reinterpret_cast<float *>(out));
 	return hipGetLastError();
 }

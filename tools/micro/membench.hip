@@ -32,10 +32,18 @@ __global__ __launch_bounds__(256) void k(const float2 *__restrict__ src, float *
 #pragma unroll
 			for (int q = 0; q < 4; q++) h[q] = hist[(size_t)e * 256 + lane + 64 * q];
 		}
-		if constexpr (V & 4) {
+		if constexpr ((V & 4) && !(V & 16)) {
 			const unsigned d = dirs[e];
 #pragma unroll
 			for (int j = 0; j < 8; j++) t[j] = tab[((size_t)d * 8 + j) * 64 + lane];
+		}
+		if constexpr ((V & 4) && (V & 16)) { // Hermitian half table: 4 KiB per direction, mirrored second half
+			const unsigned d = dirs[e];
+			const float4 *base = tab + (size_t)d * 256;
+#pragma unroll
+			for (int j = 0; j < 4; j++) t[j] = base[j * 64 + lane];
+#pragma unroll
+			for (int j = 4; j < 8; j++) { int p = 512 - (lane + 64 * j); p = p == 256 ? 0 : p; t[j] = base[p]; }
 		}
 	};
 	auto consume = [&](int e) {
@@ -97,7 +105,14 @@ int main(int argc, char **argv) {
 	printf("n=%d rows (%.1f MB of rows per launch); back-to-back launches, time per launch incl. ~launch gaps\n", n, row_mb);
 #define R(V, spw) { float us = run<V>(srcs, hist, tab, dirs, out, n, spw, 200); double mb = row_mb + ((V & 2) ? n * 2048.0 / 1e6 : 0); \
 	printf("V=%2d spw=%2d  %7.2f us  rows+hist %.0f MB -> %.2f TB/s%s%s%s%s\n", V, spw, us, mb, mb / us / 1e6 * 1e6 / 1e6, (V & 1) ? " 16B" : " 8B", (V & 2) ? " +hist" : "", (V & 4) ? " +table" : "", (V & 8) ? " +prefetch" : ""); }
-	R(0, 4) R(1, 4) R(8, 4) R(9, 4) R(0, 1) R(1, 1) R(0, 2) R(8, 8)
-	R(2, 4) R(10, 4) R(4, 4) R(12, 4) R(6, 4) R(14, 4) R(14, 2) R(14, 8) R(15, 4)
+	R(0, 4) R(8, 4)
+	R(2, 4) R(6, 4) R(14, 4)
+	printf("-- half table, random directions\n");
+	R(22, 4) R(30, 4)
+	// sorted directions: consecutive sources share a direction in runs of 8
+	for (int i = 0; i < n; i++) hd[i] = (unsigned)(i / 8) & 1023;
+	CK(hipMemcpy(dirs, hd.data(), n * 4, hipMemcpyHostToDevice));
+	printf("-- directions sorted (runs of 8)\n");
+	R(14, 4) R(30, 4)
 	return 0;
 }

@@ -13,5 +13,5 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- p
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch -o fetch -- python3 $REPO/bench.py $ARGS > $OUT/fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write -o write -- python3 $REPO/bench.py $ARGS > $OUT/write.log 2>&1
 cd $REPO
-python3 tools/summarize_profile.py $OUT > $OUT/summary.txt
+python3 tools/summarize_profile.py $OUT $OUT/pmc.json > $OUT/summary.txt
 cat $OUT/summary.txt
