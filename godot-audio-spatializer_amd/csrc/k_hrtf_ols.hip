@@ -51,6 +51,21 @@ __device__ __forceinline__ float2 cmul(float2 a, float2 b) {
 __device__ __forceinline__ float2 cmulc(float2 a, float2 b) { // a * conj(b)
 	return make_float2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y);
 }
+// Once-touched streams (source rows, history) bypass the caches' retention so they do not evict the HRIR
+// spectra table, which is the only data re-read across sources (MI355X_MICROARCH.md nt-weights row).
+#ifdef GAS_USE_NT // measured: no effect on MI355X for this kernel (profiles/r01_notes.md); kept as a switch
+#define GAS_NT_LOAD(p) __builtin_nontemporal_load(p)
+#define GAS_NT_STORE(v, p) __builtin_nontemporal_store(v, p)
+#else
+#define GAS_NT_LOAD(p) (*(p))
+#define GAS_NT_STORE(v, p) (*(p) = (v))
+#endif
+__device__ __forceinline__ gas_audio_frame nt_load_frame(const gas_audio_frame *p) {
+	typedef float v2f __attribute__((ext_vector_type(2)));
+	const v2f v = GAS_NT_LOAD(reinterpret_cast<const v2f *>(p));
+	return gas_audio_frame{ v.x, v.y };
+}
+
 // multiply by -i (forward) / +i (inverse)
 template <bool INV>
 __device__ __forceinline__ float2 rot(float2 a) {
@@ -340,9 +355,10 @@ __device__ __forceinline__ void hrtf_body(float2 *lds_all, const uint32_t wg, co
 		lm.slot = g.slots[e];
 		lm.row = g.rows ? g.rows[e] : e;
 		const gas_params *P = st.params + lm.slot;
+		const float2 gd = *reinterpret_cast<const float2 *>(&P->hrtf_gain); // hrtf_gain, hrtf_dir: one 8-byte load
 		lm.g0 = st.hrtf_prev_gain[lm.slot];
-		lm.g1 = P->hrtf_gain;
-		const uint32_t d = P->hrtf_dir;
+		lm.g1 = gd.x;
+		const uint32_t d = __float_as_uint(gd.y);
 		lm.dir = d < tab.dirs ? d : 0;
 	}
 	SrcMeta m{};
@@ -350,11 +366,13 @@ __device__ __forceinline__ void hrtf_body(float2 *lds_all, const uint32_t wg, co
 		m = bcast_meta(lm, 0);
 #pragma unroll
 		for (int q = 0; q < HQ; q++) {
-			rawh[q] = st.hrtf_hist[(size_t)m.slot * HL + lane + 64 * q];
+			rawh[q] = GAS_NT_LOAD(&st.hrtf_hist[(size_t)m.slot * HL + lane + 64 * q]);
 		}
+		if constexpr (!WITH_ER) {
 #pragma unroll
-		for (int q = 0; q < FQ; q++) {
-			raw[q] = g.src[(size_t)m.row * F + lane + 64 * q];
+			for (int q = 0; q < FQ; q++) {
+				raw[q] = nt_load_frame(&g.src[(size_t)m.row * F + lane + 64 * q]);
+			}
 		}
 		issue_spectra(tab.spec, m.dir, lane, hs);
 	}
@@ -419,7 +437,7 @@ __device__ __forceinline__ void hrtf_body(float2 *lds_all, const uint32_t wg, co
 		// new history = x_full[F .. F + HL)
 #pragma unroll
 		for (int q = 0; q < HQ; q++) {
-			st.hrtf_hist[(size_t)m.slot * HL + lane + 64 * q] = xq[FQ + q];
+			GAS_NT_STORE(xq[FQ + q], &st.hrtf_hist[(size_t)m.slot * HL + lane + 64 * q]);
 		}
 		if (lane == 0) {
 			st.hrtf_prev_gain[m.slot] = m.g1;
@@ -428,12 +446,12 @@ __device__ __forceinline__ void hrtf_body(float2 *lds_all, const uint32_t wg, co
 		if (has_next) {
 #pragma unroll
 			for (int q = 0; q < HQ; q++) {
-				rawh[q] = st.hrtf_hist[(size_t)mn.slot * HL + lane + 64 * q];
+				rawh[q] = GAS_NT_LOAD(&st.hrtf_hist[(size_t)mn.slot * HL + lane + 64 * q]);
 			}
 			if constexpr (!WITH_ER) {
 #pragma unroll
 				for (int q = 0; q < FQ; q++) {
-					raw[q] = g.src[(size_t)mn.row * F + lane + 64 * q];
+					raw[q] = nt_load_frame(&g.src[(size_t)mn.row * F + lane + 64 * q]);
 				}
 			}
 		}
@@ -530,16 +548,26 @@ __device__ __forceinline__ void hrtf_body(float2 *lds_all, const uint32_t wg, co
 		}
 		__syncthreads();
 		float *outp = reinterpret_cast<float *>(lds_all + FD_F2 + 2 * LDS_F2_HALF);
+		// every wave folds one eighth of the bins over the WAVES spectra (fixed order), into slot 0
+		{
+			constexpr int PER_THREAD = 2 * 512 / (WAVES * 64); // 2 ears x 512 bins over the workgroup
+#pragma unroll
+			for (int r = 0; r < PER_THREAD; r++) {
+				const int idx = threadIdx.x + r * WAVES * 64; // ear * 512 + bin
+				float2 sacc = fd[idx];
+#pragma unroll
+				for (int w = 1; w < WAVES; w++) {
+					sacc = cadd(sacc, fd[w * 2 * 512 + idx]);
+				}
+				fd[idx] = sacc; // only this thread touches column idx: no hazard
+			}
+		}
+		__syncthreads();
 		if (wave < 2) {
 			float2 y[8];
 #pragma unroll
 			for (int j = 0; j < 8; j++) {
-				float2 s = fd[(0 * 2 + wave) * 512 + j * 64 + lane];
-#pragma unroll
-				for (int w = 1; w < WAVES; w++) {
-					s = cadd(s, fd[(w * 2 + wave) * 512 + j * 64 + lane]);
-				}
-				y[j] = s;
+				y[j] = fd[wave * 512 + j * 64 + lane];
 			}
 			fft512<true>(y, t1, t2, lds_all + FD_F2 + wave * LDS_F2_HALF, lane);
 #pragma unroll

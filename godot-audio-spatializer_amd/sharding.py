@@ -44,6 +44,13 @@ class PartialMixReducer:
     def reduce(self, t):
         if self.world == 1:
             return None
+        if t.is_cuda and self.dist.get_backend() == "gloo":
+            # rehearsal on a box without enough GPUs for RCCL: stage through the host (synchronous)
+            h = t.cpu()
+            self.dist.reduce(h, dst=self.root, op=self.dist.ReduceOp.SUM)
+            if self.dist.get_rank() == self.root:
+                t.copy_(h)
+            return None
         if self.comm_stream is not None:
             import torch
 
