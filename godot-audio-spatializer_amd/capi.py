@@ -81,6 +81,47 @@ class Profile(C.Structure):
     ]
 
 
+SPAT3D_CONFIG_DTYPE = np.dtype(
+    [
+        ("attenuation_model", np.int32),
+        ("unit_size", np.float32),
+        ("max_distance", np.float32),
+        ("panning_strength", np.float32),
+        ("emission_angle_enabled", np.int32),
+        ("emission_angle", np.float32),
+        ("emission_angle_filter_attenuation_db", np.float32),
+        ("attenuation_filter_cutoff_hz", np.float32),
+        ("attenuation_filter_db", np.float32),
+        ("doppler_tracking", np.int32),
+        ("doppler_speed_of_sound", np.float32),
+        ("global_panning_strength", np.float32),
+        ("speaker_mode", np.int32),
+        ("hrtf_n_az", np.uint32),
+        ("hrtf_n_el", np.uint32),
+        ("reserved", np.uint32),
+    ]
+)
+POSE_DTYPE = np.dtype([("position", np.float32, (3,)), ("volume_db", np.float32), ("velocity", np.float32, (3,)), ("max_db", np.float32), ("forward", np.float32, (3,)), ("pitch_scale", np.float32)])
+LISTENER_DTYPE = np.dtype([("basis", np.float32, (3, 3)), ("origin", np.float32, (3,)), ("velocity", np.float32, (3,)), ("pad", np.float32)])
+assert SPAT3D_CONFIG_DTYPE.itemsize == 64 and POSE_DTYPE.itemsize == 48 and LISTENER_DTYPE.itemsize == 64
+
+
+def default_spat3d_config(n=1, **kw):
+    """AudioSpatializer3D defaults (audio_spatializer_3d.h:171-187), stereo, global panning strength 0.5."""
+    c = np.zeros(n, SPAT3D_CONFIG_DTYPE)
+    c["unit_size"] = 10.0
+    c["panning_strength"] = 1.0
+    c["emission_angle"] = 45.0
+    c["emission_angle_filter_attenuation_db"] = -12.0
+    c["attenuation_filter_cutoff_hz"] = 5000.0
+    c["attenuation_filter_db"] = -24.0
+    c["doppler_speed_of_sound"] = 343.0
+    c["global_panning_strength"] = 0.5
+    for k, v in kw.items():
+        c[k] = v
+    return c
+
+
 # every symbol include/gas_amd.h declares
 EXPORTS = [
     "gas_abi_version",
@@ -98,6 +139,7 @@ EXPORTS = [
     "gas_params_publish",
     "gas_params_publish_batch",
     "gas_hrtf_load",
+    "gas_calc_spatialization",
     "gas_process_block",
     "gas_process_frames_1",
     "gas_mix_channel_1",
@@ -159,6 +201,7 @@ def load_library():
     L.gas_params_publish.argtypes = [vp, u32, vp]
     L.gas_params_publish_batch.argtypes = [vp, vp, vp, u32, i32]
     L.gas_hrtf_load.argtypes = [vp, vp, u32, u32]
+    L.gas_calc_spatialization.argtypes = [vp, vp, u32, vp, vp, vp, u32, vp, u32, vp, i32]
     L.gas_process_block.argtypes = [vp, vp, vp, u32, u32, vp, vp, i32]
     L.gas_process_frames_1.argtypes = [vp, u32, vp, vp, i32]
     L.gas_mix_channel_1.argtypes = [vp, u32, i32, vp, vp, i32]
@@ -247,6 +290,18 @@ class SpatializerContext:
             s = np.ascontiguousarray(slots, dtype=np.uint32)
             sp = _np_ptr(s)
         self._check(self.lib.gas_params_publish_batch(self.h, sp, C.c_void_p(params_dev_ptr), n, MEM_DEVICE), "gas_params_publish_batch")
+
+    def calc_spatialization(self, cfgs, poses, listeners, slots, cfg_index=None, want_params=True):
+        """Host-array form of gas_calc_spatialization; returns the generated gas_params rows (or None)."""
+        cfgs = np.ascontiguousarray(cfgs, dtype=SPAT3D_CONFIG_DTYPE)
+        poses = np.ascontiguousarray(poses, dtype=POSE_DTYPE)
+        listeners = np.ascontiguousarray(listeners, dtype=LISTENER_DTYPE)
+        slots = np.ascontiguousarray(slots, dtype=np.uint32)
+        ci = np.ascontiguousarray(cfg_index, dtype=np.uint32) if cfg_index is not None else None
+        out = np.zeros(len(slots), PARAMS_DTYPE) if want_params else None
+        rc = self.lib.gas_calc_spatialization(self.h, _np_ptr(cfgs), len(cfgs), _np_ptr(ci) if ci is not None else None, _np_ptr(poses), _np_ptr(listeners), len(listeners), _np_ptr(slots), len(slots), _np_ptr(out) if want_params else None, MEM_HOST)
+        self._check(rc, "gas_calc_spatialization")
+        return out
 
     def hrtf_load(self, hrir):
         h = np.ascontiguousarray(hrir, dtype=np.float32)

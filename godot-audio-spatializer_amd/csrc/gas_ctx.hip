@@ -90,6 +90,14 @@ struct gas_ctx {
 	// one-source compatibility path
 	uint32_t *d_one_slot = nullptr;
 
+	// gas_calc_spatialization staging (physics thread)
+	std::mutex calc_mu;
+	gas_spatializer3d_config *d_calc_cfgs = nullptr;
+	gas_listener *d_calc_listeners = nullptr;
+	uint32_t *d_calc_slots = nullptr, *d_calc_cfgidx = nullptr;
+	gas_source_pose *d_calc_poses = nullptr;
+	gas_params *d_calc_out = nullptr;
+
 	bool profiling = false;
 	std::vector<hipEvent_t> ev;
 	uint32_t ev_used = 0;
@@ -505,6 +513,13 @@ void gas_ctx_destroy(gas_ctx *c) {
 	(void)hipFree(c->d_peaks);
 	(void)hipFree(c->d_partials);
 	(void)hipFree(c->d_one_slot);
+	(void)hipFree(c->st.was_further);
+	(void)hipFree(c->d_calc_cfgs);
+	(void)hipFree(c->d_calc_listeners);
+	(void)hipFree(c->d_calc_slots);
+	(void)hipFree(c->d_calc_cfgidx);
+	(void)hipFree(c->d_calc_poses);
+	(void)hipFree(c->d_calc_out);
 	(void)hipHostFree(c->h_params);
 	(void)hipHostFree(c->h_upload);
 	(void)hipHostFree(c->h_upload_slots);
@@ -567,6 +582,12 @@ int gas_ctx_create(const gas_config *cfg, gas_ctx **out_ctx) {
 		GAS_HIP(c, hipMalloc(&c->d_out, sizeof(gas_audio_frame) * cfg->channel_count * cfg->frames));
 		GAS_HIP(c, hipMalloc(&c->d_peaks, sizeof(float) * 2 * N));
 		GAS_HIP(c, hipMalloc(&c->d_one_slot, sizeof(uint32_t)));
+		GAS_HIP(c, hipMalloc(&c->st.was_further, N));
+		GAS_HIP(c, hipMemsetAsync(c->st.was_further, 0, N, c->stream));
+		GAS_HIP(c, hipMalloc(&c->d_calc_cfgs, sizeof(gas_spatializer3d_config) * GAS_MAX_SPATIALIZER_CONFIGS));
+		GAS_HIP(c, hipMalloc(&c->d_calc_listeners, sizeof(gas_listener) * GAS_MAX_LISTENERS));
+		GAS_HIP(c, hipMalloc(&c->d_calc_slots, sizeof(uint32_t) * N));
+		GAS_HIP(c, hipMalloc(&c->d_calc_cfgidx, sizeof(uint32_t) * N));
 		GAS_HIP(c, hipHostMalloc(&c->h_params, sizeof(gas_params) * N, hipHostMallocDefault));
 		GAS_HIP(c, hipHostMalloc(&c->h_upload, sizeof(gas_params) * N, hipHostMallocDefault));
 		GAS_HIP(c, hipHostMalloc(&c->h_upload_slots, sizeof(uint32_t) * N, hipHostMallocDefault));
@@ -758,6 +779,65 @@ int gas_params_publish_batch(gas_ctx *c, const uint32_t *slots, const gas_params
 			return GAS_ERR_INVALID_ARGUMENT;
 		}
 		GAS_HIP(c, gas_launch_scatter_params(c->stream, c->st.params, params, c->cached_identity_rows ? c->d_slots : c->d_slots_rows, n));
+	}
+	return GAS_OK;
+}
+
+int gas_calc_spatialization(gas_ctx *c, const gas_spatializer3d_config *cfgs, uint32_t n_cfgs, const uint32_t *cfg_index, const gas_source_pose *poses, const gas_listener *listeners, uint32_t n_listeners, const uint32_t *slots, uint32_t n, gas_params *out_params, int mem) {
+	if (!c || !cfgs || !poses || !slots || (n_listeners && !listeners) || (mem != GAS_MEM_HOST && mem != GAS_MEM_DEVICE)) {
+		return GAS_ERR_INVALID_ARGUMENT;
+	}
+	if (n_cfgs == 0 || n_cfgs > GAS_MAX_SPATIALIZER_CONFIGS || n_listeners > GAS_MAX_LISTENERS || n > c->cfg.max_sources) {
+		return GAS_ERR_INVALID_ARGUMENT;
+	}
+	for (uint32_t i = 0; i < n_cfgs; i++) {
+		if (cfgs[i].speaker_mode < 0 || cfgs[i].speaker_mode > 3 || !(cfgs[i].unit_size > 0.0f)) {
+			return GAS_ERR_INVALID_ARGUMENT;
+		}
+	}
+	for (uint32_t i = 0; i < n; i++) {
+		if (slots[i] >= c->cfg.max_sources || !c->slots[slots[i]].used) {
+			return GAS_ERR_BAD_SLOT;
+		}
+		if (cfg_index && cfg_index[i] >= n_cfgs) {
+			return GAS_ERR_INVALID_ARGUMENT;
+		}
+	}
+	if (n == 0) {
+		return GAS_OK;
+	}
+	std::lock_guard<std::mutex> lk(c->calc_mu);
+	GAS_HIP(c, hipSetDevice(c->cfg.device));
+	GAS_HIP(c, hipMemcpyAsync(c->d_calc_cfgs, cfgs, sizeof(gas_spatializer3d_config) * n_cfgs, hipMemcpyHostToDevice, c->stream));
+	if (n_listeners) {
+		GAS_HIP(c, hipMemcpyAsync(c->d_calc_listeners, listeners, sizeof(gas_listener) * n_listeners, hipMemcpyHostToDevice, c->stream));
+	}
+	GAS_HIP(c, hipMemcpyAsync(c->d_calc_slots, slots, sizeof(uint32_t) * n, hipMemcpyHostToDevice, c->stream));
+	if (cfg_index) {
+		GAS_HIP(c, hipMemcpyAsync(c->d_calc_cfgidx, cfg_index, sizeof(uint32_t) * n, hipMemcpyHostToDevice, c->stream));
+	}
+	const gas_source_pose *d_poses = poses;
+	gas_params *d_out = out_params;
+	if (mem == GAS_MEM_HOST) {
+		if (!c->d_calc_poses) {
+			GAS_HIP(c, hipMalloc(&c->d_calc_poses, sizeof(gas_source_pose) * c->cfg.max_sources));
+		}
+		GAS_HIP(c, hipMemcpyAsync(c->d_calc_poses, poses, sizeof(gas_source_pose) * n, hipMemcpyHostToDevice, c->stream));
+		d_poses = c->d_calc_poses;
+		if (out_params) {
+			if (!c->d_calc_out) {
+				GAS_HIP(c, hipMalloc(&c->d_calc_out, sizeof(gas_params) * c->cfg.max_sources));
+			}
+			d_out = c->d_calc_out;
+		}
+	}
+	GAS_HIP(c, gas_launch_calc_spatialization(c->stream, c->d_calc_cfgs, cfg_index ? c->d_calc_cfgidx : nullptr, d_poses, c->d_calc_listeners, n_listeners, c->d_calc_slots, n, c->st.params, c->st.was_further, d_out));
+	if (mem == GAS_MEM_HOST && out_params) {
+		GAS_HIP(c, hipMemcpyAsync(out_params, c->d_calc_out, sizeof(gas_params) * n, hipMemcpyDeviceToHost, c->stream));
+	}
+	GAS_HIP(c, hipStreamSynchronize(c->stream)); // the host staging arrays are the caller's
+	for (uint32_t i = 0; i < n; i++) {
+		c->slots[slots[i]].has_params = 1;
 	}
 	return GAS_OK;
 }

@@ -30,6 +30,7 @@ struct gas_dev_state {
 	gas_audio_frame *er_ring; // [max_sources][er_ring_frames]
 	uint32_t *er_pos; // [max_sources]
 	gas_params *params; // [max_sources]
+	uint8_t *was_further; // [max_sources] was_further_than_max_distance_last_frame (audio_spatializer_3d.h:118)
 };
 
 // What a launch group (one kind/chain) needs.
@@ -73,5 +74,6 @@ void gas_make_twiddles(float2 *host_tw /* [64][16] */);
 
 hipError_t gas_launch_mix_reduce(hipStream_t stream, const float *partials, uint32_t p_count, uint32_t p_stride, uint32_t channels, uint32_t frames, gas_audio_frame *out);
 hipError_t gas_launch_scatter_params(hipStream_t stream, gas_params *table, const gas_params *upload, const uint32_t *slots, uint32_t n);
+hipError_t gas_launch_calc_spatialization(hipStream_t stream, const gas_spatializer3d_config *cfgs, const uint32_t *cfg_index, const gas_source_pose *poses, const gas_listener *listeners, uint32_t n_listeners, const uint32_t *slots, uint32_t n, gas_params *table, uint8_t *was_further, gas_params *out_params);
 hipError_t gas_launch_noop(hipStream_t stream); // event-timer calibration
 hipError_t gas_launch_zero_slot(hipStream_t stream, const gas_dev_state &st, uint32_t slot, uint32_t hist_len, uint32_t er_ring_frames);

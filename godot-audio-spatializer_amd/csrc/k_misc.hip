@@ -76,6 +76,7 @@ __global__ void k_zero_slot(gas_dev_state st, uint32_t slot, uint32_t hist_len, 
 		st.hrtf_hist[(size_t)slot * hist_len + t] = 0.0f;
 	}
 	if (t == 0) {
+		st.was_further[slot] = 0;
 		st.hrtf_prev_gain[slot] = 0.0f;
 		if (st.er_pos) {
 			st.er_pos[slot] = 0;

@@ -171,6 +171,52 @@ int gas_process_block(gas_ctx *ctx, const gas_audio_frame *src, const uint32_t *
 int gas_process_frames_1(gas_ctx *ctx, uint32_t slot, gas_audio_frame *out, const gas_audio_frame *src, int frame_count);
 int gas_mix_channel_1(gas_ctx *ctx, uint32_t slot, int channel, gas_audio_frame *out, const gas_audio_frame *src, int frame_count);
 
+
+/* ---- batched parameter generation on the device ---------------------------------
+ * The arithmetic of AudioSpatializerInstance3D::calculate_spatialization (audio_spatializer_3d.cpp:277-489)
+ * for n sources against n_listeners listeners in one launch: distance attenuation models (:123-151),
+ * max-distance cut (:361-374), high-shelf gain (:376-388), emission cone (:378-385), stereo pan law
+ * (:103-110), SPCAP surround (:56-98, :903-938), doppler pitch (:405-438), update_parameters latch
+ * (:472-479).  Physics queries (Area3D override / reverb send) stay on the host.  Results are written
+ * straight into the slots' device-resident parameters (as gas_params_publish would) and optionally
+ * copied to out_params for the host's get_bus_map (audio_spatializer.cpp:274-324). */
+typedef struct gas_spatializer3d_config { /* AudioSpatializer3D properties, audio_spatializer_3d.h:171-187 */
+	int32_t attenuation_model; /* 0 inverse distance, 1 inverse square distance, 2 logarithmic, 3 disabled */
+	float unit_size, max_distance, panning_strength;
+	int32_t emission_angle_enabled;
+	float emission_angle, emission_angle_filter_attenuation_db;
+	float attenuation_filter_cutoff_hz, attenuation_filter_db;
+	int32_t doppler_tracking; /* 0 = disabled */
+	float doppler_speed_of_sound;
+	float global_panning_strength; /* project setting audio/general/3d_panning_strength (audio_spatializer_3d.cpp:633) */
+	int32_t speaker_mode; /* [ENGINE] AudioServer::SpeakerMode: 0 stereo, 1 3.1, 2 5.1, 3 7.1 */
+	uint32_t hrtf_n_az, hrtf_n_el; /* NEW: azimuth x elevation grid of the loaded HRIR set; 0 = do not write hrtf_gain / hrtf_dir */
+	uint32_t reserved;
+} gas_spatializer3d_config;
+
+typedef struct gas_source_pose {
+	float position[3]; /* player global origin */
+	float volume_db; /* AudioStreamPlayerSpatial volume_db */
+	float velocity[3]; /* tracked linear velocity (used when doppler_tracking != 0) */
+	float max_db;
+	float forward[3]; /* player global basis column 2 (emission cone axis) */
+	float pitch_scale;
+} gas_source_pose;
+
+typedef struct gas_listener { /* orthonormalized global transform of the camera / AudioListener3D */
+	float basis[3][3]; /* basis[r][c]; global = basis * local + origin */
+	float origin[3];
+	float velocity[3];
+	float pad;
+} gas_listener;
+
+#define GAS_MAX_LISTENERS 16
+#define GAS_MAX_SPATIALIZER_CONFIGS 64
+
+/* cfgs, cfg_index ([n] or NULL = config 0 for all), listeners and slots are host arrays; poses (and out_params,
+ * [n] gas_params, may be NULL) are host or device pointers according to `mem`.  Physics thread. */
+int gas_calc_spatialization(gas_ctx *ctx, const gas_spatializer3d_config *cfgs, uint32_t n_cfgs, const uint32_t *cfg_index, const gas_source_pose *poses, const gas_listener *listeners, uint32_t n_listeners, const uint32_t *slots, uint32_t n, gas_params *out_params, int mem);
+
 /* ---- measurement ------------------------------------------------------- */
 /* on = 0 off, 1 = bracket the dominant launch of every callback with HIP events, N > 1 = of every Nth callback. */
 int gas_profile_enable(gas_ctx *ctx, int on);

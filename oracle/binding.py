@@ -134,6 +134,30 @@ class Instance(C.Structure):
     ]
 
 
+class Spat3DConfig(C.Structure):
+    _fields_ = [
+        ("attenuation_model", C.c_int32),
+        ("unit_size", C.c_float),
+        ("max_distance", C.c_float),
+        ("panning_strength", C.c_float),
+        ("emission_angle_enabled", C.c_int32),
+        ("emission_angle", C.c_float),
+        ("emission_angle_filter_attenuation_db", C.c_float),
+        ("attenuation_filter_cutoff_hz", C.c_float),
+        ("attenuation_filter_db", C.c_float),
+        ("doppler_tracking", C.c_int32),
+        ("doppler_speed_of_sound", C.c_float),
+        ("global_panning_strength", C.c_float),
+        ("speaker_mode", C.c_int32),
+        ("hrtf_n_az", C.c_uint32),
+        ("hrtf_n_el", C.c_uint32),
+        ("reserved", C.c_uint32),
+    ]
+
+
+assert C.sizeof(Spat3DConfig) == 64
+
+
 class BatchState(C.Structure):
     _fields_ = [("pd3d", PData3D), ("pdfx", PDataEffect)]
 
@@ -185,6 +209,8 @@ def lib():
     L.gaso_get_mixed_frames.argtypes = [C.POINTER(Instance), C.POINTER(C.POINTER(Params)), C.POINTER(C.POINTER(Playback)), C.c_int, C.c_int, C.c_void_p, C.c_int]
     L.gaso_bus_map.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
     L.gaso_batch_block.argtypes = [C.c_int, C.c_int, C.c_void_p, C.POINTER(BatchState), C.POINTER(Hrtf), C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.gaso_calc_spatialization.restype = C.c_int
+    L.gaso_calc_spatialization.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int32), C.c_void_p]
     L.gaso_hrtf_prepare.argtypes = [C.POINTER(Hrtf), C.c_int]
     L.gaso_hrtf_release.argtypes = [C.POINTER(Hrtf)]
     L.gaso_hrtf_ols_radix2.argtypes = [C.POINTER(Params), C.POINTER(FxState), C.POINTER(Hrtf), C.c_void_p, C.c_void_p, C.c_int]
@@ -259,3 +285,18 @@ class BatchOracle:
             _ptr(peaks),
         )
         return mix, peaks, mix64
+
+
+def calc_spatialization(cfgs, cfg_index, poses, listeners, was_further, out_params):
+    """Row-by-row gaso_calc_spatialization over numpy structured arrays laid out like the product's PODs
+    (64-byte config, 48-byte pose, 64-byte listener, 128-byte params).  was_further: int32[n], updated in place.
+    Returns in_range[n]."""
+    n = len(poses)
+    L = lib()
+    in_range = np.zeros(n, np.int32)
+    for i in range(n):
+        ci = int(cfg_index[i]) if cfg_index is not None else 0
+        wf = C.c_int32(int(was_further[i]))
+        in_range[i] = L.gaso_calc_spatialization(cfgs.ctypes.data + 64 * ci, poses.ctypes.data + 48 * i, listeners.ctypes.data, len(listeners), C.byref(wf), out_params.ctypes.data + 128 * i)
+        was_further[i] = wf.value
+    return in_range

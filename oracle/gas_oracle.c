@@ -775,3 +775,226 @@ void gaso_hrtf_release(gaso_hrtf *hrtf) {
 	hrtf->spec = NULL;
 	hrtf->spec_len = 0;
 }
+
+/* ------------------------------------------------------------------ */
+/* calculate_spatialization arithmetic (audio_spatializer_3d.cpp)       */
+/* real_t = float; the pan law is double (:104-109).                    */
+/* ------------------------------------------------------------------ */
+#define GASO_CMP_EPSILON 0.00001 /* [ENGINE] CMP_EPSILON */
+
+typedef struct {
+	float x, y, z;
+} v3;
+
+static float v3_len(v3 a) {
+	return sqrtf(a.x * a.x + a.y * a.y + a.z * a.z);
+}
+
+static v3 v3_normalized(v3 a) { /* [ENGINE] Vector3::normalized: zero stays zero */
+	float l2 = a.x * a.x + a.y * a.y + a.z * a.z;
+	if (l2 == 0) {
+		v3 z = { 0, 0, 0 };
+		return z;
+	}
+	float l = sqrtf(l2);
+	v3 r = { a.x / l, a.y / l, a.z / l };
+	return r;
+}
+
+static float v3_dot(v3 a, v3 b) {
+	return a.x * b.x + a.y * b.y + a.z * b.z;
+}
+
+/* [ENGINE] Basis::xform_inv for an orthonormal basis: transposed product */
+static v3 basis_xform_inv(const float b[3][3], v3 v) {
+	v3 r = { b[0][0] * v.x + b[1][0] * v.y + b[2][0] * v.z, b[0][1] * v.x + b[1][1] * v.y + b[2][1] * v.z, b[0][2] * v.x + b[1][2] * v.y + b[2][2] * v.z };
+	return r;
+}
+
+/* audio_spatializer_3d.cpp:123-151 */
+static float get_attenuation_db(const gaso_spat3d_config *cfg, const gaso_source_pose *s, float p_distance) {
+	float att = 0;
+	switch (cfg->attenuation_model) {
+		case 0:
+			att = (float)(log(1.0 / ((p_distance / cfg->unit_size) + GASO_CMP_EPSILON)) * 8.6858896380650365530225783783321);
+			break;
+		case 1: {
+			float d = (p_distance / cfg->unit_size);
+			d *= d;
+			att = (float)(log(1.0 / (d + GASO_CMP_EPSILON)) * 8.6858896380650365530225783783321);
+		} break;
+		case 2:
+			att = (float)(-20 * log(p_distance / cfg->unit_size + GASO_CMP_EPSILON));
+			break;
+		default:
+			break;
+	}
+	att += s->volume_db;
+	if (att > s->max_db) {
+		att = s->max_db;
+	}
+	return att;
+}
+
+static const float spcap_dirs[7][3] = { /* :46-54, normalized below */
+	{ -1.0f, 0.0f, -1.0f }, { 1.0f, 0.0f, -1.0f }, { 0.0f, 0.0f, -1.0f }, { -1.0f, 0.0f, 1.0f }, { 1.0f, 0.0f, 1.0f }, { -1.0f, 0.0f, 0.0f }, { 1.0f, 0.0f, 0.0f }
+};
+
+/* calc_output_vol (:112-121) -> stereo pan law (:103-110) or SPCAP (:56-98, :903-938); out[4][2] pre-zeroed */
+static void calc_output_vol(const gaso_spat3d_config *cfg, v3 source_dir, float out[4][2]) {
+	if (cfg->speaker_mode == 0) {
+		float pan_strength = cfg->global_panning_strength * cfg->panning_strength;
+		double flatrad = sqrt(source_dir.x * source_dir.x + source_dir.z * source_dir.z);
+		double g = (1.0 - pan_strength) * (1.0 - pan_strength);
+		g = g < 0.0 ? 0.0 : (g > 1.0 ? 1.0 : g);
+		double f = (1.0 - g) / (1.0 + g);
+		double cosx = source_dir.x / (flatrad == 0.0 ? 1.0 : flatrad);
+		cosx = cosx < -1.0 ? -1.0 : (cosx > 1.0 ? 1.0 : cosx);
+		double fcosx = cosx * f;
+		out[0][0] = (float)sqrt((-fcosx + 1.0) / 2.0);
+		out[0][1] = (float)sqrt((fcosx + 1.0) / 2.0);
+		return;
+	}
+	float tightness = cfg->global_panning_strength * 2.0f;
+	tightness *= cfg->panning_strength;
+	static const int counts[4] = { 2, 3, 5, 7 };
+	int n = counts[cfg->speaker_mode];
+	v3 dirs[7];
+	float eff[7], sq[7], volumes[7];
+	for (int i = 0; i < n; i++) {
+		v3 d = { spcap_dirs[i][0], spcap_dirs[i][1], spcap_dirs[i][2] };
+		dirs[i] = v3_normalized(d);
+	}
+	for (int i = 0; i < n; i++) { /* :910-914 */
+		float e = 0.0f;
+		for (int j = 0; j < n; j++) {
+			e += (float)(0.5 * (1.0 + v3_dot(dirs[i], dirs[j])));
+		}
+		eff[i] = e;
+	}
+	float sum_sq = 0.0f;
+	for (int i = 0; i < n; i++) { /* :928-932 */
+		float initial_gain = (float)(0.5 * pow(1.0 + v3_dot(dirs[i], source_dir), tightness) / eff[i]);
+		sq[i] = initial_gain * initial_gain;
+		sum_sq += sq[i];
+	}
+	for (int i = 0; i < n; i++) {
+		volumes[i] = sqrtf(sq[i] / sum_sq);
+	}
+	if (cfg->speaker_mode >= 3) { /* :82-97 */
+		out[3][0] = volumes[5];
+		out[3][1] = volumes[6];
+	}
+	if (cfg->speaker_mode >= 2) {
+		out[2][0] = volumes[3];
+		out[2][1] = volumes[4];
+	}
+	if (cfg->speaker_mode >= 1) {
+		out[1][0] = volumes[2];
+		out[1][1] = 1.0f;
+	}
+	out[0][0] = volumes[0];
+	out[0][1] = volumes[1];
+}
+
+int gaso_calc_spatialization(const gaso_spat3d_config *cfg, const gaso_source_pose *s, const gaso_listener *listeners, int n_listeners, int32_t *was_further, gaso_params *out) {
+	v3 global_pos = { s->position[0], s->position[1], s->position[2] };
+	v3 linear_velocity = { 0, 0, 0 };
+	if (cfg->doppler_tracking != 0) { /* :295-297 */
+		linear_velocity.x = s->velocity[0];
+		linear_velocity.y = s->velocity[1];
+		linear_velocity.z = s->velocity[2];
+	}
+	float log_pitch_scale = 0.0f, log_pitch_weight = 0.0f;
+	float output_volume[4][2] = { { 0 } };
+	int has_any_listener_in_range = 0;
+	out->linear_attenuation = 0.0f; /* a fresh SpatializerParameters3D (audio_spatializer_3d.h:67-68) */
+	out->attenuation_filter_cutoff_hz = 5000.0f;
+	float best_mult = -1.0f;
+	v3 best_local = { 0, 0, -1 };
+
+	for (int li = 0; li < n_listeners; li++) {
+		const gaso_listener *L = &listeners[li];
+		v3 rel = { global_pos.x - L->origin[0], global_pos.y - L->origin[1], global_pos.z - L->origin[2] };
+		v3 local_pos = basis_xform_inv(L->basis, rel); /* :343 */
+		float dist = v3_len(local_pos);
+		float multiplier = gaso_db_to_linear(get_attenuation_db(cfg, s, dist)); /* :359 */
+		if (cfg->max_distance > 0) { /* :361-374 (no Area3D: total_max == max_distance) */
+			float total_max = cfg->max_distance;
+			if (dist > total_max) {
+				continue;
+			}
+			double m = 1.0 - (dist / cfg->max_distance);
+			multiplier = (float)(multiplier * (m > 0 ? m : 0));
+		}
+		has_any_listener_in_range = 1;
+		float db_att = (float)((1.0 - (1.0 < multiplier ? 1.0 : multiplier)) * cfg->attenuation_filter_db); /* :376 */
+		if (cfg->emission_angle_enabled) { /* :378-385 */
+			v3 fw = { s->forward[0], s->forward[1], s->forward[2] };
+			float c = v3_dot(v3_normalized(rel), v3_normalized(fw));
+			float angle = acosf(c) * (float)(180.0 / 3.14159265358979323846);
+			if (angle > cfg->emission_angle) {
+				db_att -= -cfg->emission_angle_filter_attenuation_db;
+			}
+		}
+		out->linear_attenuation = gaso_db_to_linear(db_att); /* :387, last listener in range wins */
+		out->attenuation_filter_cutoff_hz = cfg->attenuation_filter_cutoff_hz; /* :388 */
+
+		float tmp_volume[4][2] = { { 0 } };
+		calc_output_vol(cfg, local_pos, tmp_volume); /* :391, local_pos is passed un-normalised */
+		for (int k = 0; k < 4; k++) { /* :393-396 */
+			tmp_volume[k][0] = multiplier * tmp_volume[k][0];
+			tmp_volume[k][1] = multiplier * tmp_volume[k][1];
+			/* _apply_max_volume (:257-265): MAX(tgt, src) = tgt > src ? tgt : src */
+			output_volume[k][0] = output_volume[k][0] > tmp_volume[k][0] ? output_volume[k][0] : tmp_volume[k][0];
+			output_volume[k][1] = output_volume[k][1] > tmp_volume[k][1] ? output_volume[k][1] : tmp_volume[k][1];
+		}
+		if (multiplier > best_mult) {
+			best_mult = multiplier;
+			best_local = local_pos;
+		}
+		if (cfg->doppler_tracking != 0) { /* :405-431 */
+			v3 dv = { linear_velocity.x - L->velocity[0], linear_velocity.y - L->velocity[1], linear_velocity.z - L->velocity[2] };
+			v3 local_velocity = basis_xform_inv(L->basis, dv);
+			if (local_velocity.x != 0 || local_velocity.y != 0 || local_velocity.z != 0) {
+				float approaching = v3_dot(v3_normalized(local_pos), v3_normalized(local_velocity));
+				float velocity = v3_len(local_velocity);
+				float dps = s->pitch_scale * cfg->doppler_speed_of_sound / (cfg->doppler_speed_of_sound + velocity * approaching);
+				dps = dps < (float)(1 / 8.0) ? (float)(1 / 8.0) : (dps > 8.0f ? 8.0f : dps);
+				float weight = 0.0f;
+				for (int k = 0; k < 4; k++) {
+					weight = tmp_volume[k][0] > weight ? tmp_volume[k][0] : weight;
+					weight = tmp_volume[k][1] > weight ? tmp_volume[k][1] : weight;
+				}
+				log_pitch_scale += weight * log2f(dps);
+				log_pitch_weight += weight;
+			}
+		}
+	}
+	if (log_pitch_weight > 0) { /* :434-438 */
+		out->pitch_scale = powf(2.0f, log_pitch_scale / log_pitch_weight);
+	} else {
+		out->pitch_scale = s->pitch_scale;
+	}
+	for (int k = 0; k < 4; k++) { /* :469 */
+		out->mix_volumes[k][0] = output_volume[k][0];
+		out->mix_volumes[k][1] = output_volume[k][1];
+	}
+	const int skip_setting_volumes = !has_any_listener_in_range && *was_further; /* :472-479 */
+	*was_further = !has_any_listener_in_range;
+	out->update_parameters = skip_setting_volumes ? 0u : 1u;
+
+	if (cfg->hrtf_n_az > 0 && cfg->hrtf_n_el > 0) { /* NEW: gain and nearest grid direction towards the loudest listener */
+		out->hrtf_gain = has_any_listener_in_range ? best_mult : 0.0f;
+		const double two_pi = 6.2831853071795864769252867666;
+		double az = atan2((double)best_local.x, (double)-best_local.z);
+		double flat = sqrt((double)best_local.x * best_local.x + (double)best_local.z * best_local.z);
+		double el = atan2((double)best_local.y, flat);
+		long ai = lround(az / two_pi * cfg->hrtf_n_az);
+		ai = ((ai % (long)cfg->hrtf_n_az) + (long)cfg->hrtf_n_az) % (long)cfg->hrtf_n_az;
+		long ei = cfg->hrtf_n_el > 1 ? lround((el + two_pi / 4) / (two_pi / 2) * (cfg->hrtf_n_el - 1)) : 0;
+		ei = ei < 0 ? 0 : (ei > (long)cfg->hrtf_n_el - 1 ? (long)cfg->hrtf_n_el - 1 : ei);
+		out->hrtf_dir = (uint32_t)(ei * cfg->hrtf_n_az + ai);
+	}
+	return has_any_listener_in_range;
+}

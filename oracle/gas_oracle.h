@@ -180,6 +180,46 @@ int gaso_get_mixed_frames(gaso_instance *inst, const gaso_params *const *params,
 /* get_bus_map factor for one bus (audio_spatializer.cpp:295-319). */
 void gaso_bus_map(int should_mix_channels, int channel, const float bus_volume[4][2], const float mix_volumes[4][2], float out[4][2]);
 
+
+/* ---- calculate_spatialization arithmetic (audio_spatializer_3d.cpp:103-151, 277-434, 903-938), SURVEY.md 8f#1 ----
+ * Physics queries (Area3D override, reverb send: :208-256, :322-331, :398-403) stay on the host and are not
+ * restated; everything that is pure arithmetic on (source pose, listener poses, resource properties) is. */
+typedef struct gaso_spat3d_config { /* AudioSpatializer3D properties (audio_spatializer_3d.h:171-187) + engine facts */
+	int32_t attenuation_model; /* 0 inverse distance, 1 inverse square, 2 logarithmic, 3 disabled (audio_spatializer_3d.h:157-162) */
+	float unit_size, max_distance, panning_strength;
+	int32_t emission_angle_enabled;
+	float emission_angle, emission_angle_filter_attenuation_db;
+	float attenuation_filter_cutoff_hz, attenuation_filter_db;
+	int32_t doppler_tracking; /* 0 disabled (audio_spatializer_3d.h:164-168) */
+	float doppler_speed_of_sound;
+	float global_panning_strength; /* audio/general/3d_panning_strength, audio_spatializer_3d.cpp:633 */
+	int32_t speaker_mode; /* [ENGINE] AudioServer::SpeakerMode: 0 stereo, 1 3.1, 2 5.1, 3 7.1 */
+	uint32_t hrtf_n_az, hrtf_n_el; /* NEW: azimuth x elevation grid of the HRIR set (0 = leave the HRTF fields alone) */
+	uint32_t reserved;
+} gaso_spat3d_config;
+
+typedef struct gaso_source_pose {
+	float position[3]; /* get_global_transform().origin, :280 */
+	float volume_db; /* AudioStreamPlayerSpatial::volume_db, :146 */
+	float velocity[3]; /* velocity_tracker linear velocity, :296 */
+	float max_db; /* :147 */
+	float forward[3]; /* get_global_transform().basis.get_column(2), :380 */
+	float pitch_scale; /* player pitch scale, :420,:433 */
+} gaso_source_pose;
+
+typedef struct gaso_listener { /* listener_node->get_global_transform().orthonormalized(), :343 */
+	float basis[3][3]; /* basis[r][c]: global = basis * local + origin */
+	float origin[3];
+	float velocity[3]; /* get_doppler_tracked_velocity(), :409-413 */
+	float pad;
+} gaso_listener;
+
+/* One source, all listeners. *was_further mirrors was_further_than_max_distance_last_frame (:474-475).
+ * Fills mix_volumes, pitch_scale, linear_attenuation, attenuation_filter_cutoff_hz, update_parameters
+ * (and hrtf_gain / hrtf_dir when a grid is configured); other fields of *out are left untouched.
+ * Returns has_any_listener_in_range. */
+int gaso_calc_spatialization(const gaso_spat3d_config *cfg, const gaso_source_pose *src, const gaso_listener *listeners, int n_listeners, int32_t *was_further, gaso_params *out);
+
 /* ---- batched convenience used by the GPU parity tests and the CPU baseline ----
  * One callback over n_src independent sources of one kind, each row of src is
  * that source's already-windowed F frames (what process_frames/mix_channel see).
