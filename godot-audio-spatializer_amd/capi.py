@@ -140,6 +140,10 @@ EXPORTS = [
     "gas_params_publish_batch",
     "gas_hrtf_load",
     "gas_calc_spatialization",
+    "gas_stream_create",
+    "gas_stream_destroy",
+    "gas_source_bind_stream",
+    "gas_process_block_streams",
     "gas_process_block",
     "gas_process_frames_1",
     "gas_mix_channel_1",
@@ -201,6 +205,10 @@ def load_library():
     L.gas_params_publish.argtypes = [vp, u32, vp]
     L.gas_params_publish_batch.argtypes = [vp, vp, vp, u32, i32]
     L.gas_hrtf_load.argtypes = [vp, vp, u32, u32]
+    L.gas_stream_create.argtypes = [vp, vp, i32, u32, C.c_uint64, C.POINTER(u32)]
+    L.gas_stream_destroy.argtypes = [vp, u32]
+    L.gas_source_bind_stream.argtypes = [vp, u32, u32, C.c_uint64]
+    L.gas_process_block_streams.argtypes = [vp, vp, u32, u32, vp, vp, vp, i32]
     L.gas_calc_spatialization.argtypes = [vp, vp, u32, vp, vp, vp, u32, vp, u32, vp, i32]
     L.gas_process_block.argtypes = [vp, vp, vp, u32, u32, vp, vp, i32]
     L.gas_process_frames_1.argtypes = [vp, u32, vp, vp, i32]
@@ -302,6 +310,34 @@ class SpatializerContext:
         rc = self.lib.gas_calc_spatialization(self.h, _np_ptr(cfgs), len(cfgs), _np_ptr(ci) if ci is not None else None, _np_ptr(poses), _np_ptr(listeners), len(listeners), _np_ptr(slots), len(slots), _np_ptr(out) if want_params else None, MEM_HOST)
         self._check(rc, "gas_calc_spatialization")
         return out
+
+    # ---- device-resident streams ----
+    def stream_create(self, pcm):
+        """pcm: int16 or float32 array [frames] (mono) or [frames][2] (stereo)."""
+        a = np.ascontiguousarray(pcm)
+        fmt = 0 if a.dtype == np.int16 else 1
+        if fmt == 1:
+            a = a.astype(np.float32)
+        ch = 1 if a.ndim == 1 else a.shape[1]
+        sid = C.c_uint32()
+        self._check(self.lib.gas_stream_create(self.h, _np_ptr(a), fmt, ch, a.shape[0], C.byref(sid)), "gas_stream_create")
+        return sid.value
+
+    def stream_destroy(self, sid):
+        self._check(self.lib.gas_stream_destroy(self.h, sid), "gas_stream_destroy")
+
+    def source_bind_stream(self, slot, sid, start_frame=0):
+        self._check(self.lib.gas_source_bind_stream(self.h, int(slot), int(sid), int(start_frame)), "gas_source_bind_stream")
+
+    def process_block_streams(self, slots):
+        s = np.ascontiguousarray(slots, dtype=np.uint32)
+        n = len(s)
+        out = np.full((self.channel_count, self.frames, 2), np.nan, dtype=np.float32)
+        peaks = np.zeros((max(n, 1), 2), dtype=np.float32)
+        hf = np.zeros(max(n, 1), dtype=np.uint8)
+        rc = self.lib.gas_process_block_streams(self.h, _np_ptr(s) if n else None, n, self.frames, _np_ptr(out), _np_ptr(peaks), _np_ptr(hf), MEM_HOST)
+        self._check(rc, "gas_process_block_streams")
+        return out, peaks[:n], hf[:n].astype(bool)
 
     def hrtf_load(self, hrir):
         h = np.ascontiguousarray(hrir, dtype=np.float32)

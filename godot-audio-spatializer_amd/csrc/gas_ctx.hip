@@ -90,6 +90,18 @@ struct gas_ctx {
 	// one-source compatibility path
 	uint32_t *d_one_slot = nullptr;
 
+	// device-resident streams and playback cursors
+	struct StreamInfo {
+		void *d_pcm = nullptr;
+		uint64_t frames = 0;
+		uint32_t format = 0, channels = 0;
+	};
+	std::vector<StreamInfo> streams;
+	gas_cursor *d_cursors = nullptr; // [max_sources]
+	std::vector<gas_cursor> h_cursors; // host mirror of the cursor arithmetic (deterministic, no read-back)
+	float *d_fade_env = nullptr; // [64]
+	uint32_t *d_stream_slots = nullptr; // callback slot list in row order
+
 	// gas_calc_spatialization staging (physics thread)
 	std::mutex calc_mu;
 	gas_spatializer3d_config *d_calc_cfgs = nullptr;
@@ -514,6 +526,12 @@ void gas_ctx_destroy(gas_ctx *c) {
 	(void)hipFree(c->d_partials);
 	(void)hipFree(c->d_one_slot);
 	(void)hipFree(c->st.was_further);
+	(void)hipFree(c->d_cursors);
+	(void)hipFree(c->d_fade_env);
+	(void)hipFree(c->d_stream_slots);
+	for (auto &s : c->streams) {
+		(void)hipFree(s.d_pcm);
+	}
 	(void)hipFree(c->d_calc_cfgs);
 	(void)hipFree(c->d_calc_listeners);
 	(void)hipFree(c->d_calc_slots);
@@ -583,6 +601,21 @@ int gas_ctx_create(const gas_config *cfg, gas_ctx **out_ctx) {
 		GAS_HIP(c, hipMalloc(&c->d_peaks, sizeof(float) * 2 * N));
 		GAS_HIP(c, hipMalloc(&c->d_one_slot, sizeof(uint32_t)));
 		GAS_HIP(c, hipMalloc(&c->st.was_further, N));
+		GAS_HIP(c, hipMalloc(&c->d_cursors, sizeof(gas_cursor) * N));
+		GAS_HIP(c, hipMemsetAsync(c->d_cursors, 0, sizeof(gas_cursor) * N, c->stream));
+		GAS_HIP(c, hipMalloc(&c->d_stream_slots, sizeof(uint32_t) * N));
+		{
+			// the reference's fade-out envelope, same f32 recurrence (audio_spatializer.cpp:382-392)
+			float env[GAS_LOOKAHEAD_BUFFER_SIZE];
+			float fadeout_base = 0.96f, fadeout_coefficient = 1, buffer_size_float = (float)GAS_LOOKAHEAD_BUFFER_SIZE, buffer_linear_fade_idx = 0.0f;
+			for (int j = 0; j < GAS_LOOKAHEAD_BUFFER_SIZE; j++) {
+				fadeout_coefficient *= fadeout_base;
+				env[j] = fadeout_coefficient * (buffer_size_float - buffer_linear_fade_idx) / buffer_size_float;
+				buffer_linear_fade_idx += 1.0f;
+			}
+			GAS_HIP(c, hipMalloc(&c->d_fade_env, sizeof(env)));
+			GAS_HIP(c, hipMemcpy(c->d_fade_env, env, sizeof(env), hipMemcpyHostToDevice));
+		}
 		GAS_HIP(c, hipMemsetAsync(c->st.was_further, 0, N, c->stream));
 		GAS_HIP(c, hipMalloc(&c->d_calc_cfgs, sizeof(gas_spatializer3d_config) * GAS_MAX_SPATIALIZER_CONFIGS));
 		GAS_HIP(c, hipMalloc(&c->d_calc_listeners, sizeof(gas_listener) * GAS_MAX_LISTENERS));
@@ -604,6 +637,7 @@ int gas_ctx_create(const gas_config *cfg, gas_ctx **out_ctx) {
 		return rc;
 	}
 	c->slots.resize(N);
+	c->h_cursors.assign(N, gas_cursor{});
 	c->stamp.assign(N, 0);
 	c->dirty_flag.assign(N, 0);
 	c->free_list.reserve(N);
@@ -838,6 +872,176 @@ int gas_calc_spatialization(gas_ctx *c, const gas_spatializer3d_config *cfgs, ui
 	GAS_HIP(c, hipStreamSynchronize(c->stream)); // the host staging arrays are the caller's
 	for (uint32_t i = 0; i < n; i++) {
 		c->slots[slots[i]].has_params = 1;
+	}
+	return GAS_OK;
+}
+
+int gas_stream_create(gas_ctx *c, const void *pcm, int format, uint32_t channels, uint64_t frames, uint32_t *out_stream) {
+	if (!c || !pcm || !out_stream || (format != GAS_PCM_S16 && format != GAS_PCM_F32) || (channels != 1 && channels != 2) || frames == 0) {
+		return GAS_ERR_INVALID_ARGUMENT;
+	}
+	GAS_HIP(c, hipSetDevice(c->cfg.device));
+	const size_t bytes = (size_t)frames * channels * (format == GAS_PCM_S16 ? 2 : 4);
+	gas_ctx::StreamInfo si;
+	GAS_HIP(c, hipMalloc(&si.d_pcm, bytes));
+	hipError_t e = hipMemcpy(si.d_pcm, pcm, bytes, hipMemcpyHostToDevice);
+	if (e != hipSuccess) {
+		(void)hipFree(si.d_pcm);
+		c->last_err = hipGetErrorString(e);
+		return GAS_ERR_DEVICE;
+	}
+	si.frames = frames;
+	si.format = (uint32_t)format;
+	si.channels = channels;
+	for (size_t i = 0; i < c->streams.size(); i++) {
+		if (!c->streams[i].d_pcm) {
+			c->streams[i] = si;
+			*out_stream = (uint32_t)i;
+			return GAS_OK;
+		}
+	}
+	c->streams.push_back(si);
+	*out_stream = (uint32_t)c->streams.size() - 1;
+	return GAS_OK;
+}
+
+int gas_stream_destroy(gas_ctx *c, uint32_t stream) {
+	if (!c) {
+		return GAS_ERR_INVALID_ARGUMENT;
+	}
+	if (stream >= c->streams.size() || !c->streams[stream].d_pcm) {
+		return GAS_ERR_BAD_SLOT;
+	}
+	GAS_HIP(c, hipSetDevice(c->cfg.device));
+	GAS_HIP(c, hipStreamSynchronize(c->stream));
+	for (gas_cursor &cur : c->h_cursors) {
+		if (cur.pcm == c->streams[stream].d_pcm) {
+			return GAS_ERR_INVALID_ARGUMENT; // still bound to a playback
+		}
+	}
+	(void)hipFree(c->streams[stream].d_pcm);
+	c->streams[stream] = gas_ctx::StreamInfo{};
+	return GAS_OK;
+}
+
+int gas_source_bind_stream(gas_ctx *c, uint32_t slot, uint32_t stream, uint64_t start_frame) {
+	if (!c) {
+		return GAS_ERR_INVALID_ARGUMENT;
+	}
+	if (slot >= c->cfg.max_sources || !c->slots[slot].used || stream >= c->streams.size() || !c->streams[stream].d_pcm) {
+		return GAS_ERR_BAD_SLOT;
+	}
+	const gas_ctx::StreamInfo &si = c->streams[stream];
+	gas_cursor cur{};
+	cur.pcm = si.d_pcm;
+	cur.frames = si.frames;
+	cur.pos = start_frame < si.frames ? start_frame : si.frames;
+	cur.start = cur.pos;
+	cur.format_channels = (si.format << 8) | si.channels;
+	cur.has_frames = 1;
+	c->h_cursors[slot] = cur;
+	GAS_HIP(c, hipSetDevice(c->cfg.device));
+	GAS_HIP(c, hipMemcpyAsync(c->d_cursors + slot, &c->h_cursors[slot], sizeof(gas_cursor), hipMemcpyHostToDevice, c->stream));
+	GAS_HIP(c, hipStreamSynchronize(c->stream));
+	if (c->slots[slot].draining) {
+		c->slots[slot].draining = 0;
+		c->cached_n = UINT32_MAX;
+	}
+	return GAS_OK;
+}
+
+int gas_process_block_streams(gas_ctx *c, const uint32_t *slots, uint32_t n, uint32_t frames, gas_audio_frame *out, float *peaks, uint8_t *has_frames, int mem) {
+	if (!c || !out || (n > 0 && !slots) || n > c->cfg.max_sources || (mem != GAS_MEM_HOST && mem != GAS_MEM_DEVICE)) {
+		return GAS_ERR_INVALID_ARGUMENT;
+	}
+	const uint32_t F = c->cfg.frames, C = c->cfg.channel_count;
+	auto fail = [&](int code) {
+		if (mem == GAS_MEM_HOST) {
+			std::memset(out, 0, (size_t)C * F * sizeof(gas_audio_frame));
+		}
+		return code;
+	};
+	if (frames != F) {
+		return fail(GAS_ERR_FRAME_COUNT);
+	}
+	for (uint32_t i = 0; i < n; i++) {
+		if (slots[i] >= c->cfg.max_sources || !c->slots[slots[i]].used) {
+			return fail(GAS_ERR_BAD_SLOT);
+		}
+		if (c->slots[slots[i]].has_params && c->h_params[slots[i]].pitch_scale != 1.0f && c->h_params[slots[i]].pitch_scale != 0.0f) {
+			return fail(GAS_ERR_UNSUPPORTED_CHAIN); // the device sampler does not resample (host path does)
+		}
+	}
+	if (hipSetDevice(c->cfg.device) != hipSuccess) {
+		return fail(GAS_ERR_NO_DEVICE);
+	}
+	// rows for this callback live in the library's staging buffer
+	const size_t need = (size_t)n * F;
+	if (need > c->d_src_frames) {
+		if (c->d_src) {
+			(void)hipStreamSynchronize(c->stream);
+			(void)hipFree(c->d_src);
+			c->d_src = nullptr;
+			c->d_src_frames = 0;
+		}
+		if (hipMalloc(&c->d_src, (need ? need : 1) * sizeof(gas_audio_frame)) != hipSuccess) {
+			return fail(GAS_ERR_OUT_OF_MEMORY);
+		}
+		c->d_src_frames = need;
+	}
+	// host mirror of the cursor arithmetic: which playbacks end inside this callback (audio_spatializer.cpp:380,398)
+	bool draining_changed = false;
+	for (uint32_t i = 0; i < n; i++) {
+		gas_cursor &cur = c->h_cursors[slots[i]];
+		if (cur.has_frames && cur.pcm) {
+			const uint64_t left = cur.frames > cur.pos ? cur.frames - cur.pos : 0;
+			const uint32_t mixed = left < F ? (uint32_t)left : F;
+			cur.pos += mixed;
+			if (mixed != F) {
+				cur.has_frames = 0;
+			}
+		} else if (!cur.pcm) {
+			cur.has_frames = 0;
+		}
+		if (!cur.has_frames && !c->slots[slots[i]].draining) {
+			c->slots[slots[i]].draining = 1; // from now on the gate reads its peak (:464)
+			draining_changed = true;
+		}
+		if (has_frames) {
+			has_frames[i] = (uint8_t)cur.has_frames;
+		}
+	}
+	if (draining_changed) {
+		c->cached_n = UINT32_MAX;
+	}
+	if (n > 0) {
+		hipError_t e = hipMemcpyAsync(c->d_stream_slots, slots, (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream);
+		if (e == hipSuccess) {
+			e = gas_launch_sample_sources(c->stream, c->d_cursors, c->d_stream_slots, n, F, c->d_fade_env, c->d_src);
+		}
+		if (e != hipSuccess) {
+			c->last_err = hipGetErrorString(e);
+			return fail(GAS_ERR_DEVICE);
+		}
+	}
+	if (mem == GAS_MEM_DEVICE) {
+		return gas_process_block(c, c->d_src, slots, n, F, out, peaks, GAS_MEM_DEVICE);
+	}
+	// host outputs: run the device path into the library's buffers, then copy back
+	int rc = gas_process_block(c, c->d_src, slots, n, F, c->d_out, c->d_peaks, GAS_MEM_DEVICE);
+	if (rc != GAS_OK) {
+		return fail(rc);
+	}
+	hipError_t e = hipMemcpyAsync(out, c->d_out, (size_t)C * F * sizeof(gas_audio_frame), hipMemcpyDeviceToHost, c->stream);
+	if (e == hipSuccess && peaks && n > 0) {
+		e = hipMemcpyAsync(peaks, c->d_peaks, (size_t)n * 2 * sizeof(float), hipMemcpyDeviceToHost, c->stream);
+	}
+	if (e == hipSuccess) {
+		e = hipStreamSynchronize(c->stream);
+	}
+	if (e != hipSuccess) {
+		c->last_err = hipGetErrorString(e);
+		return fail(GAS_ERR_DEVICE);
 	}
 	return GAS_OK;
 }

@@ -75,5 +75,15 @@ void gas_make_twiddles(float2 *host_tw /* [64][16] */);
 hipError_t gas_launch_mix_reduce(hipStream_t stream, const float *partials, uint32_t p_count, uint32_t p_stride, uint32_t channels, uint32_t frames, gas_audio_frame *out);
 hipError_t gas_launch_scatter_params(hipStream_t stream, gas_params *table, const gas_params *upload, const uint32_t *slots, uint32_t n);
 hipError_t gas_launch_calc_spatialization(hipStream_t stream, const gas_spatializer3d_config *cfgs, const uint32_t *cfg_index, const gas_source_pose *poses, const gas_listener *listeners, uint32_t n_listeners, const uint32_t *slots, uint32_t n, gas_params *table, uint8_t *was_further, gas_params *out_params);
+// Device-resident playback cursor: what SpatialPlaybackListNode + the engine's sampler hold.
+struct gas_cursor {
+	const void *pcm; // stream base in HBM
+	uint64_t frames; // stream length
+	uint64_t pos; // frames consumed so far (fresh-frame cursor; the DSP sees pos - 64)
+	uint64_t start; // first frame of this playback: the lookahead in front of it is zero (audio_spatializer.cpp:61-63)
+	uint32_t format_channels; // format << 8 | channels
+	uint32_t has_frames; // audio_spatializer.h:63
+};
+hipError_t gas_launch_sample_sources(hipStream_t stream, gas_cursor *cursors, const uint32_t *slots, uint32_t n, uint32_t frames, const float *fade_env, gas_audio_frame *rows);
 hipError_t gas_launch_noop(hipStream_t stream); // event-timer calibration
 hipError_t gas_launch_zero_slot(hipStream_t stream, const gas_dev_state &st, uint32_t slot, uint32_t hist_len, uint32_t er_ring_frames);

@@ -217,6 +217,30 @@ typedef struct gas_listener { /* orthonormalized global transform of the camera 
  * [n] gas_params, may be NULL) are host or device pointers according to `mem`.  Physics thread. */
 int gas_calc_spatialization(gas_ctx *ctx, const gas_spatializer3d_config *cfgs, uint32_t n_cfgs, const uint32_t *cfg_index, const gas_source_pose *poses, const gas_listener *listeners, uint32_t n_listeners, const uint32_t *slots, uint32_t n, gas_params *out_params, int mem);
 
+
+/* ---- device-resident source sampling ------------------------------------------------
+ * The step in front of the path: AudioStreamPlayback::mix into the 64-frame lookahead window with the
+ * end-of-stream fade-out (audio_spatializer.cpp:367-408), over PCM that already lives in HBM, so a callback
+ * moves no source frames over PCIe.  Streams are 16-bit PCM as in the reference's example asset
+ * (speech_orig.wav: mono, 16-bit, 48 kHz); samples convert as s / 32768, mono feeds both ears [ENGINE].
+ * Only pitch_scale == 1 at the context's mix rate is sampled on the device this round (no resampler);
+ * anything else stays on the host path (gas_process_block with GAS_MEM_HOST). */
+typedef enum gas_pcm_format {
+	GAS_PCM_S16 = 0, /* interleaved little-endian int16 */
+	GAS_PCM_F32 = 1, /* interleaved float32 (already decoded) */
+} gas_pcm_format;
+
+int gas_stream_create(gas_ctx *ctx, const void *pcm, int format, uint32_t channels /* 1 or 2 */, uint64_t frames, uint32_t *out_stream);
+int gas_stream_destroy(gas_ctx *ctx, uint32_t stream);
+/* start_playback_stream (audio_spatializer.cpp:55-63): the slot's playback starts at start_frame of the stream
+ * with a zeroed lookahead and has_frames set. */
+int gas_source_bind_stream(gas_ctx *ctx, uint32_t slot, uint32_t stream, uint64_t start_frame);
+/* Like gas_process_block, but the source windows are produced on the device from the bound streams (cursor
+ * advance, lookahead delay, fade-out, zero feed after the end).  has_frames ([n] bytes, host, may be NULL)
+ * receives each playback's has_frames flag after this callback (audio_spatializer.cpp:398); slots whose
+ * stream ended are marked draining automatically.  out / peaks are host or device pointers per `mem`. */
+int gas_process_block_streams(gas_ctx *ctx, const uint32_t *slots, uint32_t n, uint32_t frames, gas_audio_frame *out, float *peaks, uint8_t *has_frames, int mem);
+
 /* ---- measurement ------------------------------------------------------- */
 /* on = 0 off, 1 = bracket the dominant launch of every callback with HIP events, N > 1 = of every Nth callback. */
 int gas_profile_enable(gas_ctx *ctx, int on);
