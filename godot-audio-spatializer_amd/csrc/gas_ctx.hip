@@ -104,6 +104,14 @@ struct gas_ctx {
 	float *d_fade_env = nullptr; // [64]
 	uint32_t *d_stream_slots = nullptr; // callback slot list in row order
 	std::vector<uint32_t> stream_slots_host; // what d_stream_slots / the cached launch groups currently hold
+	bool fused_streams = false; // this callback's HRTF launch samples the bound streams itself (no materialised rows)
+	struct StreamRow { // compact mirror of the cached list's cursors: the per-callback host loop touches only this
+		uint64_t remaining = 0;
+		uint32_t has_frames = 0, draining_marked = 0;
+	};
+	std::vector<StreamRow> stream_rows;
+	bool stream_all_hrtf = false;
+	bool stream_params_touched = false; // a parameter publish may have changed pitch_scale: re-validate
 
 	// gas_calc_spatialization staging (physics thread)
 	std::mutex calc_mu;
@@ -323,7 +331,7 @@ int run_groups(gas_ctx *c, const gas_audio_frame *d_src, const uint32_t *d_slots
 					g_pk.slots = d_slots + gp.offset;
 					g_pk.n = gp.count;
 				}
-				e = gas_launch_hrtf_ols(c->stream, fd_gt == G_FX_ER_HRTF, g_fd, g_pk, c->st, c->tab, c->d_tw, F, c->hist_len, c->cfg.er_ring_frames, c->d_partials, p_off);
+				e = gas_launch_hrtf_ols(c->stream, fd_gt == G_FX_ER_HRTF, g_fd, g_pk, c->st, c->tab, c->d_tw, F, c->hist_len, c->cfg.er_ring_frames, c->d_partials, p_off, fd_gt == G_FX_HRTF && c->fused_streams ? c->d_cursors : nullptr, c->d_fade_env);
 			} break;
 			case G_FX_ER:
 				e = gas_launch_er_only(c->stream, ga, c->st, F, c->cfg.er_ring_frames, c->d_partials, p_off, c->partial_rows);
@@ -761,6 +769,7 @@ int gas_params_publish(gas_ctx *c, uint32_t slot, const gas_params *params) {
 		return GAS_ERR_BAD_SLOT;
 	}
 	std::lock_guard<std::mutex> lk(c->params_mu);
+	c->stream_params_touched = true;
 	c->h_params[slot] = *params;
 	if (!c->dirty_flag[slot]) {
 		c->dirty_flag[slot] = 1;
@@ -784,6 +793,7 @@ int gas_params_publish_batch(gas_ctx *c, const uint32_t *slots, const gas_params
 			}
 		}
 		std::lock_guard<std::mutex> lk(c->params_mu);
+		c->stream_params_touched = true;
 		for (uint32_t i = 0; i < n; i++) {
 			const uint32_t s = slots[i];
 			c->h_params[s] = params[i];
@@ -880,6 +890,11 @@ int gas_calc_spatialization(gas_ctx *c, const gas_spatializer3d_config *cfgs, ui
 	return GAS_OK;
 }
 
+static void stream_rows_sync_back(gas_ctx *c);
+static inline void stream_rows_sync_back_fwd(gas_ctx *c) {
+	stream_rows_sync_back(c);
+}
+
 int gas_stream_create(gas_ctx *c, const void *pcm, int format, uint32_t channels, uint64_t frames, uint32_t *out_stream) {
 	if (!c || !pcm || !out_stream || (format != GAS_PCM_S16 && format != GAS_PCM_F32) || (channels != 1 && channels != 2) || frames == 0) {
 		return GAS_ERR_INVALID_ARGUMENT;
@@ -935,6 +950,8 @@ int gas_source_bind_stream(gas_ctx *c, uint32_t slot, uint32_t stream, uint64_t 
 	if (slot >= c->cfg.max_sources || !c->slots[slot].used || stream >= c->streams.size() || !c->streams[stream].d_pcm) {
 		return GAS_ERR_BAD_SLOT;
 	}
+	stream_rows_sync_back_fwd(c);
+	c->stream_groups_gen = UINT64_MAX;
 	const gas_ctx::StreamInfo &si = c->streams[stream];
 	gas_cursor cur{};
 	cur.pcm = si.d_pcm;
@@ -954,6 +971,19 @@ int gas_source_bind_stream(gas_ctx *c, uint32_t slot, uint32_t stream, uint64_t 
 	return GAS_OK;
 }
 
+// Write the compact per-row mirror of the cached stream list back into the per-slot cursors.
+static void stream_rows_sync_back(gas_ctx *c) {
+	for (size_t i = 0; i < c->stream_rows.size(); i++) {
+		gas_cursor &cur = c->h_cursors[c->stream_slots_host[i]];
+		const gas_ctx::StreamRow &r = c->stream_rows[i];
+		if (cur.pcm) {
+			cur.pos = cur.frames - r.remaining;
+		}
+		cur.has_frames = r.has_frames;
+	}
+	c->stream_rows.clear();
+}
+
 int gas_process_block_streams(gas_ctx *c, const uint32_t *slots, uint32_t n, uint32_t frames, gas_audio_frame *out, float *peaks, uint8_t *has_frames, int mem) {
 	if (!c || !out || (n > 0 && !slots) || n > c->cfg.max_sources || (mem != GAS_MEM_HOST && mem != GAS_MEM_DEVICE)) {
 		return GAS_ERR_INVALID_ARGUMENT;
@@ -968,83 +998,103 @@ int gas_process_block_streams(gas_ctx *c, const uint32_t *slots, uint32_t n, uin
 	if (frames != F) {
 		return fail(GAS_ERR_FRAME_COUNT);
 	}
-	for (uint32_t i = 0; i < n; i++) {
-		if (slots[i] >= c->cfg.max_sources || !c->slots[slots[i]].used) {
-			return fail(GAS_ERR_BAD_SLOT);
-		}
-		if (c->slots[slots[i]].has_params && c->h_params[slots[i]].pitch_scale != 1.0f && c->h_params[slots[i]].pitch_scale != 0.0f) {
-			return fail(GAS_ERR_UNSUPPORTED_CHAIN); // the device sampler does not resample (host path does)
-		}
-	}
 	if (hipSetDevice(c->cfg.device) != hipSuccess) {
 		return fail(GAS_ERR_NO_DEVICE);
 	}
-	// rows for this callback live in the library's staging buffer
-	const size_t need = (size_t)n * F;
-	if (need > c->d_src_frames) {
-		if (c->d_src) {
-			(void)hipStreamSynchronize(c->stream);
-			(void)hipFree(c->d_src);
-			c->d_src = nullptr;
-			c->d_src_frames = 0;
+	// Steady state: same slot list as the previous stream callback, launch groups still cached, no parameter or
+	// binding change since -> skip validation and work on the compact row mirror.
+	bool same_list = c->stream_rows.size() == n && c->cached_n == n && c->stream_groups_gen == c->groups_gen && !c->stream_params_touched && c->stream_slots_host.size() == n && (n == 0 || std::memcmp(c->stream_slots_host.data(), slots, (size_t)n * sizeof(uint32_t)) == 0);
+	if (!same_list) {
+		stream_rows_sync_back(c);
+		for (uint32_t i = 0; i < n; i++) {
+			if (slots[i] >= c->cfg.max_sources || !c->slots[slots[i]].used) {
+				return fail(GAS_ERR_BAD_SLOT);
+			}
+			if (c->slots[slots[i]].has_params && c->h_params[slots[i]].pitch_scale != 1.0f && c->h_params[slots[i]].pitch_scale != 0.0f) {
+				return fail(GAS_ERR_UNSUPPORTED_CHAIN); // the device sampler does not resample (the host path does)
+			}
 		}
-		if (hipMalloc(&c->d_src, (need ? need : 1) * sizeof(gas_audio_frame)) != hipSuccess) {
-			return fail(GAS_ERR_OUT_OF_MEMORY);
+		c->stream_params_touched = false;
+		c->stream_slots_host.assign(slots, slots + n);
+		c->stream_rows.resize(n);
+		c->stream_all_hrtf = n > 0;
+		for (uint32_t i = 0; i < n; i++) {
+			const gas_cursor &cur = c->h_cursors[slots[i]];
+			c->stream_rows[i].remaining = cur.pcm && cur.frames > cur.pos ? cur.frames - cur.pos : 0;
+			c->stream_rows[i].has_frames = cur.pcm ? cur.has_frames : 0;
+			c->stream_all_hrtf = c->stream_all_hrtf && c->slots[slots[i]].group == G_FX_HRTF;
 		}
-		c->d_src_frames = need;
+		if (n > 0) {
+			hipError_t e = hipMemcpyAsync(c->d_stream_slots, c->stream_slots_host.data(), (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream);
+			if (e != hipSuccess) {
+				c->last_err = hipGetErrorString(e);
+				return fail(GAS_ERR_DEVICE);
+			}
+		}
 	}
 	// host mirror of the cursor arithmetic: which playbacks end inside this callback (audio_spatializer.cpp:380,398)
 	bool draining_changed = false;
 	for (uint32_t i = 0; i < n; i++) {
-		gas_cursor &cur = c->h_cursors[slots[i]];
-		if (cur.has_frames && cur.pcm) {
-			const uint64_t left = cur.frames > cur.pos ? cur.frames - cur.pos : 0;
-			const uint32_t mixed = left < F ? (uint32_t)left : F;
-			cur.pos += mixed;
+		gas_ctx::StreamRow &r = c->stream_rows[i];
+		if (r.has_frames) {
+			const uint32_t mixed = r.remaining < F ? (uint32_t)r.remaining : F;
+			r.remaining -= mixed;
 			if (mixed != F) {
-				cur.has_frames = 0;
+				r.has_frames = 0;
 			}
-		} else if (!cur.pcm) {
-			cur.has_frames = 0;
 		}
-		if (!cur.has_frames && !c->slots[slots[i]].draining) {
-			c->slots[slots[i]].draining = 1; // from now on the gate reads its peak (:464)
-			draining_changed = true;
+		if (!r.has_frames && !r.draining_marked) {
+			r.draining_marked = 1;
+			if (!c->slots[slots[i]].draining) {
+				c->slots[slots[i]].draining = 1; // from now on the gate reads its peak (:464)
+				draining_changed = true;
+			}
 		}
 		if (has_frames) {
-			has_frames[i] = (uint8_t)cur.has_frames;
+			has_frames[i] = (uint8_t)r.has_frames;
 		}
 	}
 	if (draining_changed) {
 		c->cached_n = UINT32_MAX;
+		same_list = false;
 	}
-	// an unchanged slot list (the steady state) re-uses the uploaded list and the cached launch groups
-	const bool same_list = !draining_changed && c->cached_n == n && c->stream_groups_gen == c->groups_gen && c->stream_slots_host.size() == n && (n == 0 || std::memcmp(c->stream_slots_host.data(), slots, (size_t)n * sizeof(uint32_t)) == 0);
-	if (n > 0) {
-		hipError_t e = hipSuccess;
-		if (!same_list) {
-			c->stream_slots_host.assign(slots, slots + n);
-			e = hipMemcpyAsync(c->d_stream_slots, c->stream_slots_host.data(), (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream);
+	// rows for this callback live in the library's staging buffer (not needed when k_hrtf_ols samples the
+	// streams itself: every playback a plain [HRTF] chain)
+	const bool all_hrtf = c->stream_all_hrtf;
+	if (!all_hrtf) {
+		const size_t need = (size_t)n * F;
+		if (need > c->d_src_frames) {
+			if (c->d_src) {
+				(void)hipStreamSynchronize(c->stream);
+				(void)hipFree(c->d_src);
+				c->d_src = nullptr;
+				c->d_src_frames = 0;
+			}
+			if (hipMalloc(&c->d_src, (need ? need : 1) * sizeof(gas_audio_frame)) != hipSuccess) {
+				return fail(GAS_ERR_OUT_OF_MEMORY);
+			}
+			c->d_src_frames = need;
 		}
-		if (e == hipSuccess) {
-			e = gas_launch_sample_sources(c->stream, c->d_cursors, c->d_stream_slots, n, F, c->d_fade_env, c->d_src);
-		}
-		if (e != hipSuccess) {
-			c->last_err = hipGetErrorString(e);
-			return fail(GAS_ERR_DEVICE);
+		if (n > 0) {
+			hipError_t e = gas_launch_sample_sources(c->stream, c->d_cursors, c->d_stream_slots, n, F, c->d_fade_env, c->d_src);
+			if (e != hipSuccess) {
+				c->last_err = hipGetErrorString(e);
+				return fail(GAS_ERR_DEVICE);
+			}
 		}
 	}
 	const uint32_t *list = same_list ? nullptr : slots;
-	if (!same_list) {
-		c->stream_slots_host.assign(slots, slots + n); // (also for n == 0)
-	}
+	const gas_audio_frame *rows = all_hrtf ? reinterpret_cast<const gas_audio_frame *>(c->d_cursors) /* unused, non-null */ : c->d_src;
+	c->fused_streams = all_hrtf;
 	if (mem == GAS_MEM_DEVICE) {
-		const int rc_dev = gas_process_block(c, c->d_src, list, n, F, out, peaks, GAS_MEM_DEVICE);
+		const int rc_dev = gas_process_block(c, rows, list, n, F, out, peaks, GAS_MEM_DEVICE);
+		c->fused_streams = false;
 		c->stream_groups_gen = rc_dev == GAS_OK ? c->groups_gen : UINT64_MAX;
 		return rc_dev;
 	}
 	// host outputs: run the device path into the library's buffers, then copy back
-	int rc = gas_process_block(c, c->d_src, list, n, F, c->d_out, c->d_peaks, GAS_MEM_DEVICE);
+	int rc = gas_process_block(c, rows, list, n, F, c->d_out, c->d_peaks, GAS_MEM_DEVICE);
+	c->fused_streams = false;
 	c->stream_groups_gen = rc == GAS_OK ? c->groups_gen : UINT64_MAX;
 	if (rc != GAS_OK) {
 		return fail(rc);

@@ -33,6 +33,16 @@ struct gas_dev_state {
 	uint8_t *was_further; // [max_sources] was_further_than_max_distance_last_frame (audio_spatializer_3d.h:118)
 };
 
+// Device-resident playback cursor (SURVEY.md 8f#2): what SpatialPlaybackListNode + the engine's sampler hold.
+struct gas_cursor {
+	const void *pcm; // stream base in HBM
+	uint64_t frames; // stream length
+	uint64_t pos; // frames consumed so far (fresh-frame cursor; the DSP sees pos - 64)
+	uint64_t start; // first frame of this playback: the lookahead in front of it is zero (audio_spatializer.cpp:61-63)
+	uint32_t format_channels; // format << 8 | channels
+	uint32_t has_frames; // audio_spatializer.h:63
+};
+
 // What a launch group (one kind/chain) needs.
 struct gas_group_args {
 	const gas_audio_frame *src; // [n_rows_total][F]
@@ -66,7 +76,7 @@ struct gas_hrtf_launch_plan {
 };
 void gas_hrtf_plan(uint32_t n_fd, uint32_t n_pk, gas_hrtf_launch_plan *plan);
 uint32_t gas_hrtf_partials(uint32_t n, uint32_t *sources_per_wave); // plan for a single-path launch (k_er_only)
-hipError_t gas_launch_hrtf_ols(hipStream_t stream, bool with_er, const gas_group_args &g_fd, const gas_group_args &g_pk, const gas_dev_state &st, const gas_hrtf_table &tab, const float2 *twiddles, uint32_t frames, uint32_t hist_len, uint32_t er_ring_frames, float *partials, uint32_t p_offset);
+hipError_t gas_launch_hrtf_ols(hipStream_t stream, bool with_er, const gas_group_args &g_fd, const gas_group_args &g_pk, const gas_dev_state &st, const gas_hrtf_table &tab, const float2 *twiddles, uint32_t frames, uint32_t hist_len, uint32_t er_ring_frames, float *partials, uint32_t p_offset, gas_cursor *cursors /* non-null: sample the bound streams in the kernel */, const float *fade_env);
 hipError_t gas_launch_er_only(hipStream_t stream, const gas_group_args &g, const gas_dev_state &st, uint32_t frames, uint32_t er_ring_frames, float *partials, uint32_t p_offset, uint32_t p_stride);
 
 hipError_t gas_launch_hrtf_table(hipStream_t stream, const float *d_hrir, uint32_t dirs, uint32_t taps, const float2 *twiddles, float4 *spec);
@@ -75,15 +85,6 @@ void gas_make_twiddles(float2 *host_tw /* [64][16] */);
 hipError_t gas_launch_mix_reduce(hipStream_t stream, const float *partials, uint32_t p_count, uint32_t p_stride, uint32_t channels, uint32_t frames, gas_audio_frame *out);
 hipError_t gas_launch_scatter_params(hipStream_t stream, gas_params *table, const gas_params *upload, const uint32_t *slots, uint32_t n);
 hipError_t gas_launch_calc_spatialization(hipStream_t stream, const gas_spatializer3d_config *cfgs, const uint32_t *cfg_index, const gas_source_pose *poses, const gas_listener *listeners, uint32_t n_listeners, const uint32_t *slots, uint32_t n, gas_params *table, uint8_t *was_further, gas_params *out_params);
-// Device-resident playback cursor (SURVEY.md 8f#2): what SpatialPlaybackListNode + the engine's sampler hold.
-struct gas_cursor {
-	const void *pcm; // stream base in HBM
-	uint64_t frames; // stream length
-	uint64_t pos; // frames consumed so far (fresh-frame cursor; the DSP sees pos - 64)
-	uint64_t start; // first frame of this playback: the lookahead in front of it is zero (audio_spatializer.cpp:61-63)
-	uint32_t format_channels; // format << 8 | channels
-	uint32_t has_frames; // audio_spatializer.h:63
-};
 hipError_t gas_launch_sample_sources(hipStream_t stream, gas_cursor *cursors, const uint32_t *slots, uint32_t n, uint32_t frames, const float *fade_env, gas_audio_frame *rows);
 hipError_t gas_launch_noop(hipStream_t stream); // event-timer calibration
 hipError_t gas_launch_zero_slot(hipStream_t stream, const gas_dev_state &st, uint32_t slot, uint32_t hist_len, uint32_t er_ring_frames);

@@ -232,6 +232,10 @@ __device__ __forceinline__ float wave_max(float v) {
 struct SrcMeta {
 	uint32_t slot, row, dir;
 	float g0, g1;
+	// device-resident stream cursor (SRC_PCM only)
+	const void *pcm;
+	uint64_t len, pos, start;
+	uint32_t fc, hf, mixed;
 };
 
 // Metadata of a wave's sources lives one-source-per-lane in VGPRs: the dependent loads
@@ -241,16 +245,109 @@ struct SrcMeta {
 struct LaneMeta {
 	uint32_t slot, row, dir;
 	float g0, g1;
+	gas_cursor cur;
 };
 
-__device__ __forceinline__ SrcMeta bcast_meta(const LaneMeta &lm, uint32_t i) {
-	SrcMeta m;
+__device__ __forceinline__ uint64_t readlane64(uint64_t v, int i) {
+	const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, i);
+	const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), i);
+	return ((uint64_t)hi << 32) | lo;
+}
+
+template <bool SRC_PCM>
+__device__ __forceinline__ SrcMeta bcast_meta(const LaneMeta &lm, uint32_t i, uint32_t F) {
+	SrcMeta m{};
 	m.slot = (uint32_t)__builtin_amdgcn_readlane((int)lm.slot, (int)i);
 	m.row = (uint32_t)__builtin_amdgcn_readlane((int)lm.row, (int)i);
 	m.dir = (uint32_t)__builtin_amdgcn_readlane((int)lm.dir, (int)i);
 	m.g0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lm.g0), (int)i));
 	m.g1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lm.g1), (int)i));
+	if constexpr (SRC_PCM) {
+		m.pcm = reinterpret_cast<const void *>(readlane64(reinterpret_cast<uint64_t>(lm.cur.pcm), (int)i));
+		m.len = readlane64(lm.cur.frames, (int)i);
+		m.pos = readlane64(lm.cur.pos, (int)i);
+		m.start = readlane64(lm.cur.start, (int)i);
+		m.fc = (uint32_t)__builtin_amdgcn_readlane((int)lm.cur.format_channels, (int)i);
+		m.hf = (uint32_t)__builtin_amdgcn_readlane((int)lm.cur.has_frames, (int)i);
+		m.hf = (m.hf && m.pcm) ? 1u : 0u;
+		const uint64_t left = m.len > m.pos ? m.len - m.pos : 0;
+		m.mixed = m.hf ? (left < F ? (uint32_t)left : F) : 0; // [ENGINE] AudioStreamPlayback::mix return value
+	}
 	return m;
+}
+
+// The F frames of the source window the DSP sees (audio_spatializer.cpp:367-408), lane l taking frames l + 64 q.
+// Float rows: the caller's [n][F] buffer.  SRC_PCM: sampled here from the HBM-resident stream -- k_sample_sources'
+// logic, fused: 64-frame lookahead delay, silence in front of the playback's start, fade-out over the last 64
+// valid frames, zero feed afterwards.  The format switch sits outside the frame loop and every load is
+// unconditional (out-of-window lanes read index 0 and are masked afterwards), so the loads issue back to back.
+template <bool SRC_PCM, int FQ>
+__device__ __forceinline__ void load_window(const gas_group_args &g, const SrcMeta &m, int lane, const float *__restrict__ fade_env, gas_audio_frame (&raw)[FQ]) {
+	constexpr uint32_t F = FQ * 64;
+	if constexpr (!SRC_PCM) {
+#pragma unroll
+		for (int q = 0; q < FQ; q++) {
+			raw[q] = nt_load_frame(&g.src[(size_t)m.row * F + lane + 64 * q]);
+		}
+	} else {
+		const void *p = m.hf ? m.pcm : static_cast<const void *>(fade_env); // any readable address when nothing plays
+		const int64_t base = (int64_t)m.pos - GAS_LOOKAHEAD_BUFFER_SIZE;
+		bool ok[FQ];
+		int64_t idx[FQ];
+#pragma unroll
+		for (int q = 0; q < FQ; q++) {
+			const uint32_t f = (uint32_t)(lane + 64 * q);
+			const int64_t si = base + f;
+			ok[q] = m.hf && (m.mixed == F || f < m.mixed + GAS_LOOKAHEAD_BUFFER_SIZE) && si >= (int64_t)m.start;
+			idx[q] = ok[q] ? si : 0;
+		}
+		const uint32_t fmt = m.fc >> 8, ch = m.fc & 0xff;
+		if (fmt == GAS_PCM_S16 && ch == 1) {
+			short x[FQ];
+#pragma unroll
+			for (int q = 0; q < FQ; q++) {
+				x[q] = static_cast<const short *>(p)[idx[q]];
+			}
+#pragma unroll
+			for (int q = 0; q < FQ; q++) {
+				const float v = (float)x[q] / 32768.0f;
+				raw[q] = gas_audio_frame{ v, v };
+			}
+		} else if (fmt == GAS_PCM_S16) {
+			short2 x[FQ];
+#pragma unroll
+			for (int q = 0; q < FQ; q++) {
+				x[q] = static_cast<const short2 *>(p)[idx[q]];
+			}
+#pragma unroll
+			for (int q = 0; q < FQ; q++) {
+				raw[q] = gas_audio_frame{ (float)x[q].x / 32768.0f, (float)x[q].y / 32768.0f };
+			}
+		} else if (ch == 1) {
+#pragma unroll
+			for (int q = 0; q < FQ; q++) {
+				const float v = static_cast<const float *>(p)[idx[q]];
+				raw[q] = gas_audio_frame{ v, v };
+			}
+		} else {
+#pragma unroll
+			for (int q = 0; q < FQ; q++) {
+				const float2 v = static_cast<const float2 *>(p)[idx[q]];
+				raw[q] = gas_audio_frame{ v.x, v.y };
+			}
+		}
+		const bool ending = m.hf && m.mixed != F; // :380-396, once per playback
+#pragma unroll
+		for (int q = 0; q < FQ; q++) {
+			const uint32_t f = (uint32_t)(lane + 64 * q);
+			float e = ok[q] ? 1.0f : 0.0f;
+			if (ending && f >= m.mixed) {
+				e *= fade_env[(f - m.mixed) & (GAS_LOOKAHEAD_BUFFER_SIZE - 1)];
+			}
+			raw[q].left *= e;
+			raw[q].right *= e;
+		}
+	}
 }
 
 // HRIR spectra table: the HRIRs are real, so H[512-k] = conj(H[k]); only bins 0..255 are stored per
@@ -307,8 +404,9 @@ struct HrtfLds {
 	static constexpr int TOTAL_F2 = PEAKS ? WAVES * LDS_F2_PER_WAVE : (FD_F2 + 2 * LDS_F2_HALF + F > WAVES * LDS_F2_PER_WAVE ? FD_F2 + 2 * LDS_F2_HALF + F : WAVES * LDS_F2_PER_WAVE);
 };
 
-template <int SQ, bool WITH_ER, bool PEAKS>
-__device__ __forceinline__ void hrtf_body(float2 *lds_all, const uint32_t wg, const gas_group_args &g, const gas_dev_state &st, const gas_hrtf_table &tab, const float2 *__restrict__ tw, uint32_t spw, uint32_t er_R, float *__restrict__ my_partial) {
+template <int SQ, bool WITH_ER, bool PEAKS, bool SRC_PCM>
+__device__ __forceinline__ void hrtf_body(float2 *lds_all, const uint32_t wg, const gas_group_args &g, const gas_dev_state &st, const gas_hrtf_table &tab, const float2 *__restrict__ tw, uint32_t spw, uint32_t er_R, float *__restrict__ my_partial, gas_cursor *__restrict__ cursors, const float *__restrict__ fade_env) {
+	static_assert(!(WITH_ER && SRC_PCM), "the early-reflection prologue reads float rows");
 	constexpr int FQ = 2 * SQ; // F / 64
 	constexpr int HQ = 8 - SQ; // hist_len / 64
 	constexpr int NQ = 8 + SQ; // (hist_len + F) / 64
@@ -349,7 +447,7 @@ __device__ __forceinline__ void hrtf_body(float2 *lds_all, const uint32_t wg, co
 	float4 hs[8]; // spectra (HL.re, HL.im, HR.re, HR.im) of bins lane + 64 j
 	gas_audio_frame raw[FQ]; // frames lane + 64 q of the source row
 	float rawh[HQ]; // history samples lane + 64 q
-	LaneMeta lm{ 0, 0, 0, 0.0f, 0.0f };
+	LaneMeta lm{};
 	if (first + lane < last) { // spw <= 64: one lane per source of this wave
 		const uint32_t e = first + lane;
 		lm.slot = g.slots[e];
@@ -360,26 +458,26 @@ __device__ __forceinline__ void hrtf_body(float2 *lds_all, const uint32_t wg, co
 		lm.g1 = gd.x;
 		const uint32_t d = __float_as_uint(gd.y);
 		lm.dir = d < tab.dirs ? d : 0;
+		if constexpr (SRC_PCM) {
+			lm.cur = cursors[lm.slot];
+		}
 	}
 	SrcMeta m{};
 	if (first < last) {
-		m = bcast_meta(lm, 0);
+		m = bcast_meta<SRC_PCM>(lm, 0, F);
 #pragma unroll
 		for (int q = 0; q < HQ; q++) {
 			rawh[q] = GAS_NT_LOAD(&st.hrtf_hist[(size_t)m.slot * HL + lane + 64 * q]);
 		}
 		if constexpr (!WITH_ER) {
-#pragma unroll
-			for (int q = 0; q < FQ; q++) {
-				raw[q] = nt_load_frame(&g.src[(size_t)m.row * F + lane + 64 * q]);
-			}
+			load_window<SRC_PCM, FQ>(g, m, lane, fade_env, raw);
 		}
 		issue_spectra(tab.spec, m.dir, lane, hs);
 	}
 
 	for (uint32_t e = first; e < last; e++) {
 		const bool has_next = e + 1 < last;
-		const SrcMeta mn = bcast_meta(lm, has_next ? e + 1 - first : e - first);
+		const SrcMeta mn = bcast_meta<SRC_PCM>(lm, has_next ? e + 1 - first : e - first, F);
 
 		// x_full[lane + 64 q]: q < HQ from the history, the rest from this callback's frames.
 		float xq[NQ];
@@ -441,6 +539,14 @@ __device__ __forceinline__ void hrtf_body(float2 *lds_all, const uint32_t wg, co
 		}
 		if (lane == 0) {
 			st.hrtf_prev_gain[m.slot] = m.g1;
+			if constexpr (SRC_PCM) {
+				if (m.hf) { // advance the playback cursor (audio_spatializer.cpp:378,398)
+					cursors[m.slot].pos = m.pos + m.mixed;
+					if (m.mixed != F) {
+						cursors[m.slot].has_frames = 0;
+					}
+				}
+			}
 		}
 		// raw buffers are free again: start the next source's frames and history
 		if (has_next) {
@@ -449,10 +555,7 @@ __device__ __forceinline__ void hrtf_body(float2 *lds_all, const uint32_t wg, co
 				rawh[q] = GAS_NT_LOAD(&st.hrtf_hist[(size_t)mn.slot * HL + lane + 64 * q]);
 			}
 			if constexpr (!WITH_ER) {
-#pragma unroll
-				for (int q = 0; q < FQ; q++) {
-					raw[q] = nt_load_frame(&g.src[(size_t)mn.row * F + lane + 64 * q]);
-				}
+				load_window<SRC_PCM, FQ>(g, mn, lane, fade_env, raw);
 			}
 		}
 
@@ -589,15 +692,15 @@ __device__ __forceinline__ void hrtf_body(float2 *lds_all, const uint32_t wg, co
 
 // One launch per callback for every HRTF source: workgroups [0, wgs_fd) run the frequency-domain body over
 // g_fd, the rest run the exact-peak body over g_pk (the draining playbacks).
-template <int SQ, bool WITH_ER>
-__global__ __launch_bounds__(WAVES * 64, GAS_HRTF_WAVES_PER_SIMD) void k_hrtf_ols(gas_group_args g_fd, gas_group_args g_pk, uint32_t wgs_fd, gas_dev_state st, gas_hrtf_table tab, const float2 *__restrict__ tw, uint32_t spw_fd, uint32_t spw_pk, uint32_t er_R, float *__restrict__ partials, uint32_t p_offset) {
+template <int SQ, bool WITH_ER, bool SRC_PCM>
+__global__ __launch_bounds__(WAVES * 64, GAS_HRTF_WAVES_PER_SIMD) void k_hrtf_ols(gas_group_args g_fd, gas_group_args g_pk, uint32_t wgs_fd, gas_dev_state st, gas_hrtf_table tab, const float2 *__restrict__ tw, uint32_t spw_fd, uint32_t spw_pk, uint32_t er_R, float *__restrict__ partials, uint32_t p_offset, gas_cursor *__restrict__ cursors, const float *__restrict__ fade_env) {
 	constexpr int LDS_F2 = HrtfLds<SQ, false>::TOTAL_F2 > HrtfLds<SQ, true>::TOTAL_F2 ? HrtfLds<SQ, false>::TOTAL_F2 : HrtfLds<SQ, true>::TOTAL_F2;
 	__shared__ float2 lds_all[LDS_F2];
 	float *my_partial = partials + ((size_t)p_offset + blockIdx.x) * (size_t)(2 * SQ * 64 * 2);
 	if (blockIdx.x < wgs_fd) {
-		hrtf_body<SQ, WITH_ER, false>(lds_all, blockIdx.x, g_fd, st, tab, tw, spw_fd, er_R, my_partial);
+		hrtf_body<SQ, WITH_ER, false, SRC_PCM>(lds_all, blockIdx.x, g_fd, st, tab, tw, spw_fd, er_R, my_partial, cursors, fade_env);
 	} else {
-		hrtf_body<SQ, WITH_ER, true>(lds_all, blockIdx.x - wgs_fd, g_pk, st, tab, tw, spw_pk, er_R, my_partial);
+		hrtf_body<SQ, WITH_ER, true, SRC_PCM>(lds_all, blockIdx.x - wgs_fd, g_pk, st, tab, tw, spw_pk, er_R, my_partial, cursors, fade_env);
 	}
 }
 
@@ -762,24 +865,28 @@ uint32_t gas_hrtf_partials(uint32_t n, uint32_t *sources_per_wave) {
 	return p.wgs_fd;
 }
 
-hipError_t gas_launch_hrtf_ols(hipStream_t stream, bool with_er, const gas_group_args &g_fd, const gas_group_args &g_pk, const gas_dev_state &st, const gas_hrtf_table &tab, const float2 *twiddles, uint32_t frames, uint32_t hist_len, uint32_t er_ring_frames, float *partials, uint32_t p_offset) {
+hipError_t gas_launch_hrtf_ols(hipStream_t stream, bool with_er, const gas_group_args &g_fd, const gas_group_args &g_pk, const gas_dev_state &st, const gas_hrtf_table &tab, const float2 *twiddles, uint32_t frames, uint32_t hist_len, uint32_t er_ring_frames, float *partials, uint32_t p_offset, gas_cursor *cursors, const float *fade_env) {
 	if (g_fd.n + g_pk.n == 0) {
 		return hipSuccess;
 	}
-	if (frames % 128 != 0 || frames > 512 || hist_len != 512 - frames / 2) {
+	if (frames % 128 != 0 || frames > 512 || hist_len != 512 - frames / 2 || (with_er && cursors)) {
 		return hipErrorInvalidValue;
 	}
 	gas_hrtf_launch_plan plan;
 	gas_hrtf_plan(g_fd.n, g_pk.n, &plan);
 	const uint32_t wgs_fd = plan.wgs_fd, spw_fd = plan.spw_fd, spw_pk = plan.spw_pk;
 	dim3 grid(plan.wgs_fd + plan.wgs_pk), block(WAVES * 64);
-#define GAS_HRTF_CASE(SQv)                                                                                                                                    \
-	case SQv:                                                                                                                                                 \
-		if (with_er) {                                                                                                                                        \
-			hipLaunchKernelGGL((k_hrtf_ols<SQv, true>), grid, block, 0, stream, g_fd, g_pk, wgs_fd, st, tab, twiddles, spw_fd, spw_pk, er_ring_frames, partials, p_offset);  \
-		} else {                                                                                                                                              \
-			hipLaunchKernelGGL((k_hrtf_ols<SQv, false>), grid, block, 0, stream, g_fd, g_pk, wgs_fd, st, tab, twiddles, spw_fd, spw_pk, er_ring_frames, partials, p_offset); \
-		}                                                                                                                                                     \
+#define GAS_HRTF_LAUNCH(SQv, ERv, PCMv) \
+	hipLaunchKernelGGL((k_hrtf_ols<SQv, ERv, PCMv>), grid, block, 0, stream, g_fd, g_pk, wgs_fd, st, tab, twiddles, spw_fd, spw_pk, er_ring_frames, partials, p_offset, cursors, fade_env)
+#define GAS_HRTF_CASE(SQv)                       \
+	case SQv:                                    \
+		if (with_er) {                           \
+			GAS_HRTF_LAUNCH(SQv, true, false);   \
+		} else if (cursors) {                    \
+			GAS_HRTF_LAUNCH(SQv, false, true);   \
+		} else {                                 \
+			GAS_HRTF_LAUNCH(SQv, false, false);  \
+		}                                        \
 		break;
 	switch (frames / 128) {
 		GAS_HRTF_CASE(1)
@@ -790,6 +897,7 @@ hipError_t gas_launch_hrtf_ols(hipStream_t stream, bool with_er, const gas_group
 			return hipErrorInvalidValue;
 	}
 #undef GAS_HRTF_CASE
+#undef GAS_HRTF_LAUNCH
 	return hipGetLastError();
 }
 

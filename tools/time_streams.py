@@ -39,7 +39,9 @@ torch.cuda.synchronize()
 t0 = time.perf_counter()
 for _ in range(steps):
     step()
+t_enq = (time.perf_counter() - t0) / steps
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / steps
+print(f"host enqueue {t_enq * 1e6:.1f} us per callback")
 print(f"device-resident PCM16 streams: {n} HRTF sources, {dt * 1e6:.1f} us per callback, {n * F / dt:.3e} AudioFrames/s (stream bytes {n * F * 2 / 1e6:.1f} MB/callback)")
 ctx.close()
