@@ -94,3 +94,35 @@ def test_synth_params_follow_reference_formulas(gas):
     p = synth.draw_params(np.random.default_rng(0), 1000, frames=256, ring_frames=4096)
     assert p["er_delay"].max() <= 4096 - 256 and p["er_delay"].min() >= 48
     assert np.all(p["linear_attenuation"] >= 10 ** (-24 / 20) - 1e-6) and np.all(p["linear_attenuation"] <= 1.0)
+
+
+def test_headers_are_c99_and_the_c_example_links(gas, tmp_path):
+    """include/*.h must be consumable by a C compiler (the reference's FFI side is C/C++), and a plain-C program must
+    link against libgas_amd.so using only what the headers declare."""
+    import shutil
+    import subprocess
+
+    gas.build.build()
+    src = os.path.join(ROOT, "examples", "abi_example.c")
+    exe = str(tmp_path / "abi_example")
+    libdir = os.path.dirname(gas.capi.library_path())
+    cmd = ["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-I" + os.path.join(ROOT, "include"), src, "-L" + libdir, "-lgas_amd", "-lm", "-Wl,-rpath," + libdir, "-Wl,--allow-shlib-undefined", "-o", exe]
+    subprocess.check_call(cmd)
+    if not os.path.exists("/dev/kfd"):  # no GPU here: the program must report it and exit cleanly
+        env = dict(os.environ, LD_LIBRARY_PATH=libdir + ":/opt/rocm/lib:" + os.environ.get("LD_LIBRARY_PATH", ""))
+        out = subprocess.run([exe], capture_output=True, text=True, env=env, timeout=120)
+        assert out.returncode == 0, out.stderr
+        assert "no usable HIP device" in out.stdout
+
+
+@pytest.mark.gpu
+def test_c_example_runs_on_the_gpu(gas, tmp_path):
+    import subprocess
+
+    src = os.path.join(ROOT, "examples", "abi_example.c")
+    exe = str(tmp_path / "abi_example")
+    libdir = os.path.dirname(gas.capi.library_path())
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-I" + os.path.join(ROOT, "include"), src, "-L" + libdir, "-lgas_amd", "-lm", "-Wl,-rpath," + libdir, "-Wl,--allow-shlib-undefined", "-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "gas_process_block: ok" in out.stdout and "gas_host_get_mixed_frames: ok" in out.stdout
