@@ -43,6 +43,8 @@ struct SlotInfo {
 
 struct Group {
 	uint32_t offset = 0, count = 0;
+	bool contiguous = false; // the group's slots are slot_base, slot_base + 1, ... in order
+	uint32_t slot_base = 0;
 };
 
 constexpr uint32_t PROFILE_EVENTS = 4096;
@@ -288,6 +290,7 @@ int run_groups(gas_ctx *c, const gas_audio_frame *d_src, const uint32_t *d_slots
 		ga.src = d_src;
 		ga.rows = d_rows ? d_rows + gr.offset : nullptr;
 		ga.slots = d_slots + gr.offset;
+		ga.slot_base = 0;
 		ga.n = gr.count;
 		ga.peaks = d_peaks;
 		const bool timed = c->profiling && gt == dom && c->ev_used + 2 <= c->ev.size() && (c->prof_tick++ % c->prof_every) == 0;
@@ -330,6 +333,15 @@ int run_groups(gas_ctx *c, const gas_audio_frame *d_src, const uint32_t *d_slots
 					g_pk.rows = d_rows ? d_rows + gp.offset : nullptr;
 					g_pk.slots = d_slots + gp.offset;
 					g_pk.n = gp.count;
+				}
+				// contiguous slot ranges need no slot list on the device (one dependent load less in the prologue)
+				if (g_fd.n && groups[fd_gt].contiguous) {
+					g_fd.slots = nullptr;
+					g_fd.slot_base = groups[fd_gt].slot_base;
+				}
+				if (g_pk.n && groups[fd_gt + 1].contiguous) {
+					g_pk.slots = nullptr;
+					g_pk.slot_base = groups[fd_gt + 1].slot_base;
 				}
 				e = gas_launch_hrtf_ols(c->stream, fd_gt == G_FX_ER_HRTF, g_fd, g_pk, c->st, c->tab, c->d_tw, F, c->hist_len, c->cfg.er_ring_frames, c->d_partials, p_off, fd_gt == G_FX_HRTF && c->fused_streams ? c->d_cursors : nullptr, c->d_fade_env);
 			} break;
@@ -444,6 +456,14 @@ int build_groups(gas_ctx *c, const uint32_t *slots, uint32_t n) {
 		const uint32_t p = cursor[launch_group(c, c->slots[slots[i]])]++;
 		hs[p] = slots[i];
 		hr[p] = i;
+	}
+	for (int gt = 0; gt < G_COUNT; gt++) {
+		Group &gr = c->groups[gt];
+		gr.contiguous = gr.count > 0;
+		gr.slot_base = gr.count ? hs[gr.offset] : 0;
+		for (uint32_t k = 1; k < gr.count && gr.contiguous; k++) {
+			gr.contiguous = hs[gr.offset + k] == gr.slot_base + k;
+		}
 	}
 	c->cached_identity_rows = nonempty <= 1;
 	if (n > 0) {

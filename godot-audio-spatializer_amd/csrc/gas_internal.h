@@ -47,7 +47,8 @@ struct gas_cursor {
 struct gas_group_args {
 	const gas_audio_frame *src; // [n_rows_total][F]
 	const uint32_t *rows; // [n] row of src per group entry, or nullptr (= identity)
-	const uint32_t *slots; // [n] slot per group entry
+	const uint32_t *slots; // [n] slot per group entry, or nullptr: slot = slot_base + entry (contiguous range)
+	uint32_t slot_base;
 	uint32_t n;
 	float *peaks; // [n_rows_total][2]
 };

@@ -447,11 +447,25 @@ __device__ __forceinline__ void hrtf_body(float2 *lds_all, const uint32_t wg, co
 	float4 hs[8]; // spectra (HL.re, HL.im, HR.re, HR.im) of bins lane + 64 j
 	gas_audio_frame raw[FQ]; // frames lane + 64 q of the source row
 	float rawh[HQ]; // history samples lane + 64 q
+	// Prologue, ordered so that no load waits behind one it does not depend on:
+	//   level 1  slot / row of each of this wave's sources (one lane per source; no load at all when the
+	//            callback's slots are a contiguous range and the rows are in order)
+	//   level 2  gain + direction + previous gain (+ stream cursor), and -- needing only level 1 -- the first
+	//            source's history and frames
+	//   level 3  the first source's spectra (consumed after the forward FFT, so they arrive under it)
 	LaneMeta lm{};
-	if (first + lane < last) { // spw <= 64: one lane per source of this wave
+	const bool have = first + lane < last; // spw <= 64: one lane per source of this wave
+	if (have) {
 		const uint32_t e = first + lane;
-		lm.slot = g.slots[e];
+		lm.slot = g.slots ? g.slots[e] : g.slot_base + e;
 		lm.row = g.rows ? g.rows[e] : e;
+	}
+	SrcMeta m{};
+	if (first < last) {
+		m.slot = (uint32_t)__builtin_amdgcn_readlane((int)lm.slot, 0);
+		m.row = (uint32_t)__builtin_amdgcn_readlane((int)lm.row, 0);
+	}
+	if (have) {
 		const gas_params *P = st.params + lm.slot;
 		const float2 gd = *reinterpret_cast<const float2 *>(&P->hrtf_gain); // hrtf_gain, hrtf_dir: one 8-byte load
 		lm.g0 = st.hrtf_prev_gain[lm.slot];
@@ -462,15 +476,17 @@ __device__ __forceinline__ void hrtf_body(float2 *lds_all, const uint32_t wg, co
 			lm.cur = cursors[lm.slot];
 		}
 	}
-	SrcMeta m{};
 	if (first < last) {
-		m = bcast_meta<SRC_PCM>(lm, 0, F);
 #pragma unroll
 		for (int q = 0; q < HQ; q++) {
 			rawh[q] = GAS_NT_LOAD(&st.hrtf_hist[(size_t)m.slot * HL + lane + 64 * q]);
 		}
-		if constexpr (!WITH_ER) {
-			load_window<SRC_PCM, FQ>(g, m, lane, fade_env, raw);
+		if constexpr (!WITH_ER && !SRC_PCM) {
+			load_window<false, FQ>(g, m, lane, fade_env, raw); // needs the row only
+		}
+		m = bcast_meta<SRC_PCM>(lm, 0, F);
+		if constexpr (!WITH_ER && SRC_PCM) {
+			load_window<true, FQ>(g, m, lane, fade_env, raw); // needs the cursor
 		}
 		issue_spectra(tab.spec, m.dir, lane, hs);
 	}
