@@ -25,8 +25,6 @@
 //
 // Bound: HBM.  Algorithmic bytes/source = F*8 (source) + 2*hist_len*4 (history r+w) + 128 (params) + 8
 // (peak) + 8 (gain state), + the ring traffic (8 taps * F * 8 read + F * 8 write) with early reflections.
-#include <cstdlib>
-
 #include "gas_internal.h"
 
 namespace {
@@ -847,13 +845,7 @@ void gas_make_twiddles(float2 *host_tw) {
 void gas_hrtf_plan(uint32_t n_fd, uint32_t n_pk, gas_hrtf_launch_plan *p) {
 	const uint32_t budget = 256u * 4u * GAS_HRTF_WAVES_PER_SIMD / WAVES;
 	auto spw_for = [](uint32_t n, uint32_t wgs) {
-		uint32_t spw = (n + wgs * WAVES - 1) / (wgs * WAVES);
-		if (const char *ov = getenv("GAS_HRTF_SPW")) { // tuning aid
-			const int v = atoi(ov);
-			if (v > 0) {
-				spw = (uint32_t)v;
-			}
-		}
+		const uint32_t spw = (n + wgs * WAVES - 1) / (wgs * WAVES);
 		return spw < 1 ? 1u : (spw > 64 ? 64u : spw);
 	};
 	p->spw_fd = p->spw_pk = 1;

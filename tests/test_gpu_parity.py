@@ -82,7 +82,7 @@ def test_effect_highshelf(gas, ob):
     run_pair(gas, ob, gas.capi.KIND_EFFECT, (gas.capi.FX_HIGHSHELF,), 77, 512, 5)
 
 
-@pytest.mark.parametrize("frames,n", [(512, 1), (512, 67), (256, 130), (512, 300)])
+@pytest.mark.parametrize("frames,n", [(512, 1), (512, 67), (256, 130), (512, 300), (128, 90), (384, 75)])
 def test_hrtf(gas, ob, frames, n):
     """cfg3 shape at oracle-friendly size: per-source 256-tap HRTF, direction redrawn every 2 callbacks."""
     from godot_audio_spatializer_amd import synth
@@ -101,6 +101,13 @@ def test_er_hrtf_cfg5(gas, ob):
 
 def test_er_only(gas, ob):
     run_pair(gas, ob, gas.capi.KIND_EFFECT, (gas.capi.FX_EARLY_REFLECTIONS,), 50, 256, 20, ring=4096, redraw_every=3)
+
+
+@pytest.mark.parametrize("frames", [128, 384])
+def test_other_block_sizes(gas, ob, frames):
+    """The context accepts any multiple of 128 up to 512 frames per callback; 512 is the engine's mix step."""
+    run_pair(gas, ob, gas.capi.KIND_3D_MIX, (), 40, frames, 4)
+    run_pair(gas, ob, gas.capi.KIND_EFFECT, (gas.capi.FX_EARLY_REFLECTIONS, gas.capi.FX_HRTF), 33, frames, 40 if frames == 128 else 14, hrir=__import__("godot_audio_spatializer_amd").synth.synthetic_hrir(np.random.default_rng(7), dirs=64), ring=4096, redraw_every=3)
 
 
 @pytest.mark.parametrize("frames,chain,ring", [(512, (3,), 0), (256, (3,), 0), (256, (2, 3), 4096)])
