@@ -97,6 +97,7 @@ def main():
     ap.add_argument("--no-max-sources", action="store_true")
     ap.add_argument("--profile-every", type=int, default=4, help="bracket the dominant kernel of every Nth step with HIP events (markers cost ~2 us each)")
     ap.add_argument("--reduce-bucket", type=int, default=8, help="callbacks per cross-GPU reduce (N > 1)")
+    ap.add_argument("--crossfade", action="store_true", help="GAS_FLAG_HRTF_CROSSFADE: blend old/new HRIRs when a source's direction changes (SURVEY 8f#4)")
     ap.add_argument("--exact-peaks", action="store_true", help="per-source inverse FFTs for every source (exact peak of every source)")
     args = ap.parse_args()
 
@@ -137,6 +138,8 @@ def main():
     # (audio_spatializer.cpp:464-469).  1 source in 64 is in that state here; the rest take the
     # frequency-domain accumulation path.  --exact-peaks measures every source's peak instead.
     flags = 0 if args.exact_peaks else gas.capi.FLAG_PEAKS_DRAINING_ONLY
+    if args.crossfade:
+        flags |= gas.capi.FLAG_HRTF_CROSSFADE
     ctx = gas.SpatializerContext(max_sources=n_local, frames=frames, channel_count=1, er_ring_frames=ring, device=local_rank, flags=flags)
     stream = torch.cuda.current_stream()
     ctx.set_stream(stream.cuda_stream)
@@ -254,6 +257,7 @@ def main():
                 "frames_per_callback": frames,
                 "sample_rate_hz": 48000,
                 "hrir_directions": args.dirs if hrir is not None else 0,
+                "hrir_crossfade": bool(args.crossfade),
                 "peaks": "every source" if args.exact_peaks else f"draining sources only ({n_draining} of {n_local} per GPU)",
                 "parallelism": f"source-sharded x{world}, RCCL sum-reduce to rank 0 of {B} callbacks' partial mixes ({B * frames * 8} B) per collective, pipelined on a side stream" if world > 1 else "single GPU",
                 "realtime_budget_ms": frames / 48000.0 * 1e3,

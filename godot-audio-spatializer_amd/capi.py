@@ -23,6 +23,7 @@ FX_HRTF = 3
 MEM_HOST = 0
 MEM_DEVICE = 1
 FLAG_PEAKS_DRAINING_ONLY = 1
+FLAG_HRTF_CROSSFADE = 2
 
 STATUS = {
     0: "GAS_OK",

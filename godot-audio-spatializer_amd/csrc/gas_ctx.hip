@@ -343,7 +343,7 @@ int run_groups(gas_ctx *c, const gas_audio_frame *d_src, const uint32_t *d_slots
 					g_pk.slots = nullptr;
 					g_pk.slot_base = groups[fd_gt + 1].slot_base;
 				}
-				e = gas_launch_hrtf_ols(c->stream, fd_gt == G_FX_ER_HRTF, g_fd, g_pk, c->st, c->tab, c->d_tw, F, c->hist_len, c->cfg.er_ring_frames, c->d_partials, p_off, fd_gt == G_FX_HRTF && c->fused_streams ? c->d_cursors : nullptr, c->d_fade_env);
+				e = gas_launch_hrtf_ols(c->stream, fd_gt == G_FX_ER_HRTF, (c->cfg.flags & GAS_FLAG_HRTF_CROSSFADE) != 0, g_fd, g_pk, c->st, c->tab, c->d_tw, F, c->hist_len, c->cfg.er_ring_frames, c->d_partials, p_off, fd_gt == G_FX_HRTF && c->fused_streams ? c->d_cursors : nullptr, c->d_fade_env);
 			} break;
 			case G_FX_ER:
 				e = gas_launch_er_only(c->stream, ga, c->st, F, c->cfg.er_ring_frames, c->d_partials, p_off, c->partial_rows);
@@ -542,6 +542,7 @@ void gas_ctx_destroy(gas_ctx *c) {
 	(void)hipFree(c->st.bq);
 	(void)hipFree(c->st.hrtf_hist);
 	(void)hipFree(c->st.hrtf_prev_gain);
+	(void)hipFree(c->st.hrtf_prev_dir);
 	(void)hipFree(c->st.er_ring);
 	(void)hipFree(c->st.er_pos);
 	(void)hipFree(c->st.params);
@@ -616,6 +617,8 @@ int gas_ctx_create(const gas_config *cfg, gas_ctx **out_ctx) {
 		GAS_HIP(c, hipMemsetAsync(c->st.hrtf_hist, 0, sizeof(float) * N * c->hist_len, c->stream));
 		GAS_HIP(c, hipMalloc(&c->st.hrtf_prev_gain, sizeof(float) * N));
 		GAS_HIP(c, hipMemsetAsync(c->st.hrtf_prev_gain, 0, sizeof(float) * N, c->stream));
+		GAS_HIP(c, hipMalloc(&c->st.hrtf_prev_dir, sizeof(uint32_t) * N));
+		GAS_HIP(c, hipMemsetAsync(c->st.hrtf_prev_dir, 0, sizeof(uint32_t) * N, c->stream));
 		if (cfg->er_ring_frames) {
 			GAS_HIP(c, hipMalloc(&c->st.er_ring, sizeof(gas_audio_frame) * N * cfg->er_ring_frames));
 			GAS_HIP(c, hipMemsetAsync(c->st.er_ring, 0, sizeof(gas_audio_frame) * N * cfg->er_ring_frames, c->stream));

@@ -229,6 +229,7 @@ __device__ __forceinline__ float wave_max(float v) {
 // Wave-uniform description of one source of the callback (scalar registers).
 struct SrcMeta {
 	uint32_t slot, row, dir;
+	uint32_t pdir; // direction of the previous callback (== dir when there was none): cross-fade source (8f#4)
 	float g0, g1;
 	// device-resident stream cursor (SRC_PCM only)
 	const void *pcm;
@@ -241,7 +242,7 @@ struct SrcMeta {
 // parallel, instead of once per source on the critical path (dependent scalar loads share lgkmcnt
 // with the FFT's LDS exchanges and cost ~16 us per launch when done per source).
 struct LaneMeta {
-	uint32_t slot, row, dir;
+	uint32_t slot, row, dir, pdir;
 	float g0, g1;
 	gas_cursor cur;
 };
@@ -258,6 +259,7 @@ __device__ __forceinline__ SrcMeta bcast_meta(const LaneMeta &lm, uint32_t i, ui
 	m.slot = (uint32_t)__builtin_amdgcn_readlane((int)lm.slot, (int)i);
 	m.row = (uint32_t)__builtin_amdgcn_readlane((int)lm.row, (int)i);
 	m.dir = (uint32_t)__builtin_amdgcn_readlane((int)lm.dir, (int)i);
+	m.pdir = (uint32_t)__builtin_amdgcn_readlane((int)lm.pdir, (int)i);
 	m.g0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lm.g0), (int)i));
 	m.g1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lm.g1), (int)i));
 	if constexpr (SRC_PCM) {
@@ -402,7 +404,7 @@ struct HrtfLds {
 	static constexpr int TOTAL_F2 = PEAKS ? WAVES * LDS_F2_PER_WAVE : (FD_F2 + 2 * LDS_F2_HALF + F > WAVES * LDS_F2_PER_WAVE ? FD_F2 + 2 * LDS_F2_HALF + F : WAVES * LDS_F2_PER_WAVE);
 };
 
-template <int SQ, bool WITH_ER, bool PEAKS, bool SRC_PCM>
+template <int SQ, bool WITH_ER, bool PEAKS, bool SRC_PCM, bool XFADE>
 __device__ __forceinline__ void hrtf_body(float2 *lds_all, const uint32_t wg, const gas_group_args &g, const gas_dev_state &st, const gas_hrtf_table &tab, const float2 *__restrict__ tw, uint32_t spw, uint32_t er_R, float *__restrict__ my_partial, gas_cursor *__restrict__ cursors, const float *__restrict__ fade_env) {
 	static_assert(!(WITH_ER && SRC_PCM), "the early-reflection prologue reads float rows");
 	constexpr int FQ = 2 * SQ; // F / 64
@@ -425,8 +427,12 @@ __device__ __forceinline__ void hrtf_body(float2 *lds_all, const uint32_t wg, co
 	}
 
 	// running sum of this wave's sources: time domain (PEAKS) or frequency domain
+	// XFADE: a source whose direction changed since its previous callback is rendered with both
+	// HRIRs and blended with t = f/F across the block.  The weights depend on the frame only, so the frequency-
+	// domain path just keeps a second spectrum sum: aY* = sum Z*H[new], bY* = sum Z*H[old] (sources whose direction
+	// did not change go into both), and the epilogue outputs t*IFFT(aY) + (1-t)*IFFT(bY).
 	float accL[FQ], accR[FQ];
-	float2 aYL[8], aYR[8];
+	float2 aYL[8], aYR[8], bYL[8], bYR[8];
 #pragma unroll
 	for (int t = 0; t < FQ; t++) {
 		accL[t] = 0.0f;
@@ -436,6 +442,8 @@ __device__ __forceinline__ void hrtf_body(float2 *lds_all, const uint32_t wg, co
 	for (int j = 0; j < 8; j++) {
 		aYL[j] = make_float2(0.0f, 0.0f);
 		aYR[j] = make_float2(0.0f, 0.0f);
+		bYL[j] = make_float2(0.0f, 0.0f);
+		bYR[j] = make_float2(0.0f, 0.0f);
 	}
 
 	const uint32_t first = (wg * WAVES + wave) * spw;
@@ -470,6 +478,11 @@ __device__ __forceinline__ void hrtf_body(float2 *lds_all, const uint32_t wg, co
 		lm.g1 = gd.x;
 		const uint32_t d = __float_as_uint(gd.y);
 		lm.dir = d < tab.dirs ? d : 0;
+		lm.pdir = lm.dir;
+		if constexpr (XFADE) {
+			const uint32_t pd = st.hrtf_prev_dir[lm.slot]; // previous direction + 1, 0 = none yet
+			lm.pdir = pd == 0 ? lm.dir : (pd - 1 < tab.dirs ? pd - 1 : 0);
+		}
 		if constexpr (SRC_PCM) {
 			lm.cur = cursors[lm.slot];
 		}
@@ -553,6 +566,9 @@ __device__ __forceinline__ void hrtf_body(float2 *lds_all, const uint32_t wg, co
 		}
 		if (lane == 0) {
 			st.hrtf_prev_gain[m.slot] = m.g1;
+			if constexpr (XFADE) {
+				st.hrtf_prev_dir[m.slot] = m.dir + 1;
+			}
 			if constexpr (SRC_PCM) {
 				if (m.hf) { // advance the playback cursor (audio_spatializer.cpp:378,398)
 					cursors[m.slot].pos = m.pos + m.mixed;
@@ -582,6 +598,7 @@ __device__ __forceinline__ void hrtf_body(float2 *lds_all, const uint32_t wg, co
 		fft512<false>(v, t1, t2, lds, lane);
 		finish_spectra(lane, hs);
 
+		const bool changed = XFADE && m.pdir != m.dir; // wave-uniform
 		if constexpr (PEAKS) {
 			float2 yl[8], yr[8];
 #pragma unroll
@@ -589,26 +606,52 @@ __device__ __forceinline__ void hrtf_body(float2 *lds_all, const uint32_t wg, co
 				yl[j] = cmul(v[j], make_float2(hs[j].x, hs[j].y));
 				yr[j] = cmul(v[j], make_float2(hs[j].z, hs[j].w));
 			}
-			// spectra registers are free again: start the next direction's table rows
-			if (has_next) {
+			// spectra registers are free again: the old direction's rows (cross-fade) or the next source's
+			if (changed) {
+				issue_spectra(tab.spec, m.pdir, lane, hs);
+			} else if (has_next) {
 				issue_spectra(tab.spec, mn.dir, lane, hs);
 			}
 			float pkl = 0.0f, pkr = 0.0f;
 			fft512_pair<true>(yl, yr, t1, t2, lds, lds + LDS_F2_HALF, lane);
 			// valid outputs are window positions [512 - S, 512): registers j >= HQ
+			float oL[FQ], oR[FQ];
 #pragma unroll
 			for (int t = 0; t < SQ; t++) {
-				const float oa = yl[HQ + t].x, ob = yl[HQ + t].y;
-				accL[t] += oa;
-				accL[SQ + t] += ob;
-				pkl = fmaxf(pkl, fmaxf(fabsf(oa), fabsf(ob)));
+				oL[t] = yl[HQ + t].x;
+				oL[SQ + t] = yl[HQ + t].y;
+				oR[t] = yr[HQ + t].x;
+				oR[SQ + t] = yr[HQ + t].y;
+			}
+			if constexpr (XFADE) {
+				if (changed) { // render the old direction too and blend, t = frame / F
+					finish_spectra(lane, hs);
+#pragma unroll
+					for (int j = 0; j < 8; j++) {
+						yl[j] = cmul(v[j], make_float2(hs[j].x, hs[j].y));
+						yr[j] = cmul(v[j], make_float2(hs[j].z, hs[j].w));
+					}
+					if (has_next) {
+						issue_spectra(tab.spec, mn.dir, lane, hs);
+					}
+					fft512_pair<true>(yl, yr, t1, t2, lds, lds + LDS_F2_HALF, lane);
+#pragma unroll
+					for (int t = 0; t < SQ; t++) {
+						const float ta = (float)(lane + 64 * t) * (1.0f / (float)F);
+						const float tb = (float)(lane + 64 * (SQ + t)) * (1.0f / (float)F);
+						oL[t] = oL[t] * ta + yl[HQ + t].x * (1 - ta);
+						oL[SQ + t] = oL[SQ + t] * tb + yl[HQ + t].y * (1 - tb);
+						oR[t] = oR[t] * ta + yr[HQ + t].x * (1 - ta);
+						oR[SQ + t] = oR[SQ + t] * tb + yr[HQ + t].y * (1 - tb);
+					}
+				}
 			}
 #pragma unroll
-			for (int t = 0; t < SQ; t++) {
-				const float oa = yr[HQ + t].x, ob = yr[HQ + t].y;
-				accR[t] += oa;
-				accR[SQ + t] += ob;
-				pkr = fmaxf(pkr, fmaxf(fabsf(oa), fabsf(ob)));
+			for (int t = 0; t < FQ; t++) {
+				accL[t] += oL[t];
+				accR[t] += oR[t];
+				pkl = fmaxf(pkl, fabsf(oL[t]));
+				pkr = fmaxf(pkr, fabsf(oR[t]));
 			}
 			pkl = wave_max(pkl);
 			pkr = wave_max(pkr);
@@ -623,6 +666,23 @@ __device__ __forceinline__ void hrtf_body(float2 *lds_all, const uint32_t wg, co
 				const float2 pr = cmul(v[j], make_float2(hs[j].z, hs[j].w));
 				aYL[j] = cadd(aYL[j], pl);
 				aYR[j] = cadd(aYR[j], pr);
+				if constexpr (XFADE) {
+					if (!changed) { // same HRIR on both sides of the fade
+						bYL[j] = cadd(bYL[j], pl);
+						bYR[j] = cadd(bYR[j], pr);
+					}
+				}
+			}
+			if constexpr (XFADE) {
+				if (changed) {
+					issue_spectra(tab.spec, m.pdir, lane, hs);
+					finish_spectra(lane, hs);
+#pragma unroll
+					for (int j = 0; j < 8; j++) {
+						bYL[j] = cadd(bYL[j], cmul(v[j], make_float2(hs[j].x, hs[j].y)));
+						bYR[j] = cadd(bYR[j], cmul(v[j], make_float2(hs[j].z, hs[j].w)));
+					}
+				}
 			}
 			if (has_next) {
 				issue_spectra(tab.spec, mn.dir, lane, hs);
@@ -655,42 +715,59 @@ __device__ __forceinline__ void hrtf_body(float2 *lds_all, const uint32_t wg, co
 		}
 	} else {
 		// spectra of all waves -> fd[wave][ear][j][lane]; then wave 0 transforms the left ear's sum and
-		// wave 1 the right ear's, and the workgroup stores one interleaved time-domain partial.
-		__syncthreads(); // every wave is done with its exchange slice (fd aliases them)
+		// wave 1 the right ear's, and the workgroup stores one interleaved time-domain partial.  With XFADE the
+		// same round runs twice: new-direction sums weighted by t = f/F, old-direction sums by 1 - t.
 		float2 *fd = lds_all;
-#pragma unroll
-		for (int j = 0; j < 8; j++) {
-			fd[(wave * 2 + 0) * 512 + j * 64 + lane] = aYL[j];
-			fd[(wave * 2 + 1) * 512 + j * 64 + lane] = aYR[j];
-		}
-		__syncthreads();
 		float *outp = reinterpret_cast<float *>(lds_all + FD_F2 + 2 * LDS_F2_HALF);
-		// every wave folds one eighth of the bins over the WAVES spectra (fixed order), into slot 0
-		{
-			constexpr int PER_THREAD = 2 * 512 / (WAVES * 64); // 2 ears x 512 bins over the workgroup
+		constexpr int ROUNDS = XFADE ? 2 : 1;
 #pragma unroll
-			for (int r = 0; r < PER_THREAD; r++) {
-				const int idx = threadIdx.x + r * WAVES * 64; // ear * 512 + bin
-				float2 sacc = fd[idx];
-#pragma unroll
-				for (int w = 1; w < WAVES; w++) {
-					sacc = cadd(sacc, fd[w * 2 * 512 + idx]);
-				}
-				fd[idx] = sacc; // only this thread touches column idx: no hazard
-			}
-		}
-		__syncthreads();
-		if (wave < 2) {
-			float2 y[8];
+		for (int round = 0; round < ROUNDS; round++) {
+			__syncthreads(); // every wave is done with its exchange slice / the previous round (fd aliases them)
 #pragma unroll
 			for (int j = 0; j < 8; j++) {
-				y[j] = fd[wave * 512 + j * 64 + lane];
+				fd[(wave * 2 + 0) * 512 + j * 64 + lane] = round == 0 ? aYL[j] : bYL[j];
+				fd[(wave * 2 + 1) * 512 + j * 64 + lane] = round == 0 ? aYR[j] : bYR[j];
 			}
-			fft512<true>(y, t1, t2, lds_all + FD_F2 + wave * LDS_F2_HALF, lane);
+			__syncthreads();
+			// every wave folds one eighth of the bins over the WAVES spectra (fixed order), into slot 0
+			{
+				constexpr int PER_THREAD = 2 * 512 / (WAVES * 64); // 2 ears x 512 bins over the workgroup
 #pragma unroll
-			for (int t = 0; t < SQ; t++) {
-				outp[(lane + 64 * t) * 2 + wave] = y[HQ + t].x;
-				outp[(lane + 64 * (SQ + t)) * 2 + wave] = y[HQ + t].y;
+				for (int r = 0; r < PER_THREAD; r++) {
+					const int idx = threadIdx.x + r * WAVES * 64; // ear * 512 + bin
+					float2 sacc = fd[idx];
+#pragma unroll
+					for (int w = 1; w < WAVES; w++) {
+						sacc = cadd(sacc, fd[w * 2 * 512 + idx]);
+					}
+					fd[idx] = sacc; // only this thread touches column idx: no hazard
+				}
+			}
+			__syncthreads();
+			if (wave < 2) {
+				float2 y[8];
+#pragma unroll
+				for (int j = 0; j < 8; j++) {
+					y[j] = fd[wave * 512 + j * 64 + lane];
+				}
+				fft512<true>(y, t1, t2, lds_all + FD_F2 + wave * LDS_F2_HALF, lane);
+#pragma unroll
+				for (int t = 0; t < SQ; t++) {
+					const int fa = lane + 64 * t, fb = lane + 64 * (SQ + t);
+					if constexpr (!XFADE) {
+						outp[fa * 2 + wave] = y[HQ + t].x;
+						outp[fb * 2 + wave] = y[HQ + t].y;
+					} else {
+						const float ta = (float)fa * (1.0f / (float)F), tb = (float)fb * (1.0f / (float)F);
+						if (round == 0) {
+							outp[fa * 2 + wave] = y[HQ + t].x * ta;
+							outp[fb * 2 + wave] = y[HQ + t].y * tb;
+						} else { // the same lane owns the same elements in both rounds
+							outp[fa * 2 + wave] += y[HQ + t].x * (1 - ta);
+							outp[fb * 2 + wave] += y[HQ + t].y * (1 - tb);
+						}
+					}
+				}
 			}
 		}
 		__syncthreads();
@@ -702,19 +779,21 @@ __device__ __forceinline__ void hrtf_body(float2 *lds_all, const uint32_t wg, co
 	(void)accR;
 	(void)aYL;
 	(void)aYR;
+	(void)bYL;
+	(void)bYR;
 }
 
 // One launch per callback for every HRTF source: workgroups [0, wgs_fd) run the frequency-domain body over
 // g_fd, the rest run the exact-peak body over g_pk (the draining playbacks).
-template <int SQ, bool WITH_ER, bool SRC_PCM>
+template <int SQ, bool WITH_ER, bool SRC_PCM, bool XFADE>
 __global__ __launch_bounds__(WAVES * 64, GAS_HRTF_WAVES_PER_SIMD) void k_hrtf_ols(gas_group_args g_fd, gas_group_args g_pk, uint32_t wgs_fd, gas_dev_state st, gas_hrtf_table tab, const float2 *__restrict__ tw, uint32_t spw_fd, uint32_t spw_pk, uint32_t er_R, float *__restrict__ partials, uint32_t p_offset, gas_cursor *__restrict__ cursors, const float *__restrict__ fade_env) {
 	constexpr int LDS_F2 = HrtfLds<SQ, false>::TOTAL_F2 > HrtfLds<SQ, true>::TOTAL_F2 ? HrtfLds<SQ, false>::TOTAL_F2 : HrtfLds<SQ, true>::TOTAL_F2;
 	__shared__ float2 lds_all[LDS_F2];
 	float *my_partial = partials + ((size_t)p_offset + blockIdx.x) * (size_t)(2 * SQ * 64 * 2);
 	if (blockIdx.x < wgs_fd) {
-		hrtf_body<SQ, WITH_ER, false, SRC_PCM>(lds_all, blockIdx.x, g_fd, st, tab, tw, spw_fd, er_R, my_partial, cursors, fade_env);
+		hrtf_body<SQ, WITH_ER, false, SRC_PCM, XFADE>(lds_all, blockIdx.x, g_fd, st, tab, tw, spw_fd, er_R, my_partial, cursors, fade_env);
 	} else {
-		hrtf_body<SQ, WITH_ER, true, SRC_PCM>(lds_all, blockIdx.x - wgs_fd, g_pk, st, tab, tw, spw_pk, er_R, my_partial, cursors, fade_env);
+		hrtf_body<SQ, WITH_ER, true, SRC_PCM, XFADE>(lds_all, blockIdx.x - wgs_fd, g_pk, st, tab, tw, spw_pk, er_R, my_partial, cursors, fade_env);
 	}
 }
 
@@ -873,7 +952,7 @@ uint32_t gas_hrtf_partials(uint32_t n, uint32_t *sources_per_wave) {
 	return p.wgs_fd;
 }
 
-hipError_t gas_launch_hrtf_ols(hipStream_t stream, bool with_er, const gas_group_args &g_fd, const gas_group_args &g_pk, const gas_dev_state &st, const gas_hrtf_table &tab, const float2 *twiddles, uint32_t frames, uint32_t hist_len, uint32_t er_ring_frames, float *partials, uint32_t p_offset, gas_cursor *cursors, const float *fade_env) {
+hipError_t gas_launch_hrtf_ols(hipStream_t stream, bool with_er, bool crossfade, const gas_group_args &g_fd, const gas_group_args &g_pk, const gas_dev_state &st, const gas_hrtf_table &tab, const float2 *twiddles, uint32_t frames, uint32_t hist_len, uint32_t er_ring_frames, float *partials, uint32_t p_offset, gas_cursor *cursors, const float *fade_env) {
 	if (g_fd.n + g_pk.n == 0) {
 		return hipSuccess;
 	}
@@ -884,17 +963,23 @@ hipError_t gas_launch_hrtf_ols(hipStream_t stream, bool with_er, const gas_group
 	gas_hrtf_plan(g_fd.n, g_pk.n, &plan);
 	const uint32_t wgs_fd = plan.wgs_fd, spw_fd = plan.spw_fd, spw_pk = plan.spw_pk;
 	dim3 grid(plan.wgs_fd + plan.wgs_pk), block(WAVES * 64);
-#define GAS_HRTF_LAUNCH(SQv, ERv, PCMv) \
-	hipLaunchKernelGGL((k_hrtf_ols<SQv, ERv, PCMv>), grid, block, 0, stream, g_fd, g_pk, wgs_fd, st, tab, twiddles, spw_fd, spw_pk, er_ring_frames, partials, p_offset, cursors, fade_env)
-#define GAS_HRTF_CASE(SQv)                       \
-	case SQv:                                    \
-		if (with_er) {                           \
-			GAS_HRTF_LAUNCH(SQv, true, false);   \
-		} else if (cursors) {                    \
-			GAS_HRTF_LAUNCH(SQv, false, true);   \
-		} else {                                 \
-			GAS_HRTF_LAUNCH(SQv, false, false);  \
-		}                                        \
+#define GAS_HRTF_LAUNCH(SQv, ERv, PCMv, XFv) \
+	hipLaunchKernelGGL((k_hrtf_ols<SQv, ERv, PCMv, XFv>), grid, block, 0, stream, g_fd, g_pk, wgs_fd, st, tab, twiddles, spw_fd, spw_pk, er_ring_frames, partials, p_offset, cursors, fade_env)
+#define GAS_HRTF_CASE3(SQv, XFv)                      \
+	if (with_er) {                                    \
+		GAS_HRTF_LAUNCH(SQv, true, false, XFv);       \
+	} else if (cursors) {                             \
+		GAS_HRTF_LAUNCH(SQv, false, true, XFv);       \
+	} else {                                          \
+		GAS_HRTF_LAUNCH(SQv, false, false, XFv);      \
+	}
+#define GAS_HRTF_CASE(SQv)              \
+	case SQv:                           \
+		if (crossfade) {                \
+			GAS_HRTF_CASE3(SQv, true)   \
+		} else {                        \
+			GAS_HRTF_CASE3(SQv, false)  \
+		}                               \
 		break;
 	switch (frames / 128) {
 		GAS_HRTF_CASE(1)
@@ -905,6 +990,7 @@ hipError_t gas_launch_hrtf_ols(hipStream_t stream, bool with_er, const gas_group
 			return hipErrorInvalidValue;
 	}
 #undef GAS_HRTF_CASE
+#undef GAS_HRTF_CASE3
 #undef GAS_HRTF_LAUNCH
 	return hipGetLastError();
 }

@@ -78,6 +78,7 @@ __global__ void k_zero_slot(gas_dev_state st, uint32_t slot, uint32_t hist_len, 
 	if (t == 0) {
 		st.was_further[slot] = 0;
 		st.hrtf_prev_gain[slot] = 0.0f;
+		st.hrtf_prev_dir[slot] = 0;
 		if (st.er_pos) {
 			st.er_pos[slot] = 0;
 		}

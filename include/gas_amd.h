@@ -99,6 +99,10 @@ typedef struct gas_config {
  * peak = +inf ("not measured", never passes the gate); the mix is unchanged.  Without it every source
  * reports its exact peak, as the reference computes it. */
 #define GAS_FLAG_PEAKS_DRAINING_ONLY 1u
+/* NEW: when an HRTF source's direction differs from the one of its previous callback, render the
+ * block with both HRIRs and blend old -> new with t = i/F (the analogue of the per-block volume lerp,
+ * audio_spatializer_3d.cpp:591-592) instead of switching at the block boundary. */
+#define GAS_FLAG_HRTF_CROSSFADE 2u
 
 /* SpatializerParameters (spatializer_parameters.h:39-67) + SpatializerParameters3D
  * (audio_spatializer_3d.h:61-83) as one 128-byte POD, plus the per-block effect

@@ -92,6 +92,7 @@ class FxState(C.Structure):
         ("ring_pos", C.c_uint32),
         ("hist", C.c_float * (HRTF_TAPS - 1)),
         ("prev_gain", C.c_float),
+        ("prev_dir_plus1", C.c_int32),
     ]
 
 
@@ -100,7 +101,7 @@ class PDataEffect(C.Structure):
 
 
 class Hrtf(C.Structure):
-    _fields_ = [("hrir", C.POINTER(C.c_float)), ("dirs", C.c_uint32), ("impl", C.c_int32), ("spec", C.POINTER(C.c_float)), ("spec_len", C.c_int32)]
+    _fields_ = [("hrir", C.POINTER(C.c_float)), ("dirs", C.c_uint32), ("impl", C.c_int32), ("spec", C.POINTER(C.c_float)), ("spec_len", C.c_int32), ("crossfade", C.c_int32)]
 
 
 class Playback(C.Structure):
@@ -222,11 +223,11 @@ def _ptr(a):
     return a.ctypes.data_as(C.c_void_p)
 
 
-def make_hrtf(hrir, impl=0):
+def make_hrtf(hrir, impl=0, crossfade=False):
     """hrir: float32 [dirs][2][256]. Returns (Hrtf struct, keepalive)."""
     hrir = np.ascontiguousarray(hrir, dtype=np.float32)
     assert hrir.ndim == 3 and hrir.shape[1] == 2 and hrir.shape[2] == HRTF_TAPS
-    h = Hrtf(hrir.ctypes.data_as(C.POINTER(C.c_float)), hrir.shape[0], impl, None, 0)
+    h = Hrtf(hrir.ctypes.data_as(C.POINTER(C.c_float)), hrir.shape[0], impl, None, 0, int(crossfade))
     h._keep = hrir
     return h
 
@@ -237,14 +238,14 @@ class BatchOracle:
     kind: KIND_3D_MIX / KIND_3D_PROCESS / KIND_EFFECT; chain: list of FX_* for KIND_EFFECT.
     """
 
-    def __init__(self, kind, n_src, frames, channel_count=1, chain=(), hrir=None, mix_rate=48000.0, er_ring_frames=4096, hrtf_impl=0):
+    def __init__(self, kind, n_src, frames, channel_count=1, chain=(), hrir=None, mix_rate=48000.0, er_ring_frames=4096, hrtf_impl=0, crossfade=False):
         self.kind = kind
         self.n_src = n_src
         self.frames = frames
         self.channel_count = channel_count if kind == KIND_3D_MIX else 1
         self.mix_rate = float(mix_rate)
         self.states = (BatchState * n_src)()
-        self.hrtf = make_hrtf(hrir, hrtf_impl) if hrir is not None else None
+        self.hrtf = make_hrtf(hrir, hrtf_impl, crossfade) if hrir is not None else None
         if self.hrtf is not None and hrtf_impl == 1:
             fft_len = 1
             while fft_len < frames + HRTF_TAPS - 1:

@@ -308,20 +308,37 @@ static void fx_hrtf(const gaso_params *params, gaso_fx_state *st, const gaso_hrt
 	float *xx = (float *)malloc(sizeof(float) * (size_t)(H + n));
 	hrtf_make_x(params, st, src, xx, n);
 	uint32_t dir = params->hrtf_dir < hrtf->dirs ? params->hrtf_dir : 0;
+	uint32_t old_dir = dir;
+	if (hrtf->crossfade && st->prev_dir_plus1 > 0) {
+		old_dir = (uint32_t)(st->prev_dir_plus1 - 1);
+	}
 	const float *hl = hrtf->hrir + (size_t)dir * 2 * T;
 	const float *hr = hl + T;
+	const float *ol = hrtf->hrir + (size_t)old_dir * 2 * T;
+	const float *orr = ol + T;
 	for (int i = 0; i < n; i++) {
-		double al = 0.0, ar = 0.0;
+		double al = 0.0, ar = 0.0, bl = 0.0, br = 0.0;
 		const float *xp = xx + H + i;
 		for (int k = 0; k < T; k++) {
 			double x = xp[-k];
 			al += (double)hl[k] * x;
 			ar += (double)hr[k] * x;
 		}
+		if (old_dir != dir) { /* cross-fade: old HRIR fades out, new fades in, t = i / n */
+			for (int k = 0; k < T; k++) {
+				double x = xp[-k];
+				bl += (double)ol[k] * x;
+				br += (double)orr[k] * x;
+			}
+			double t = (double)((float)i / n);
+			al = al * t + bl * (1.0 - t);
+			ar = ar * t + br * (1.0 - t);
+		}
 		dst[i].l = (float)al;
 		dst[i].r = (float)ar;
 	}
 	hrtf_commit(params, st, xx, n);
+	st->prev_dir_plus1 = (int32_t)dir + 1;
 	free(xx);
 }
 
@@ -751,6 +768,7 @@ void gaso_hrtf_ols_radix2(const gaso_params *params, gaso_fx_state *st, const ga
 		}
 	}
 	hrtf_commit(params, st, xx, n);
+	st->prev_dir_plus1 = (int32_t)dir + 1;
 	free(buf);
 	free(xx);
 }

@@ -97,6 +97,7 @@ typedef struct gaso_fx_state {
 	/* HRTF: last TAPS-1 gained mono samples + previous gain */
 	float hist[GASO_HRTF_TAPS - 1];
 	float prev_gain;
+	int32_t prev_dir_plus1; /* 0 = no previous callback yet; else previous hrtf_dir + 1 (cross-fade) */
 } gaso_fx_state;
 
 typedef struct gaso_pdata_effect {
@@ -112,6 +113,9 @@ typedef struct gaso_hrtf {
 	int32_t impl; /* 0: direct-form f64 FIR (the checker); 1: overlap-save radix-2 FFT in f32 (the CPU baseline) */
 	float *spec; /* impl 1 only: cached HRIR spectra [dirs][2 ears][re|im][spec_len], built by gaso_hrtf_prepare */
 	int32_t spec_len;
+	int32_t crossfade; /* NEW (8f#4): when a playback's direction changed since its previous callback, blend the old
+	                      and the new HRIR's outputs with t = i/n across the block (the volume lerp's analogue,
+	                      audio_spatializer_3d.cpp:591-592) instead of switching at the block boundary */
 } gaso_hrtf;
 
 /* ---- engine primitives ------------------------------------------------ */

@@ -13,16 +13,23 @@ pytestmark = pytest.mark.gpu
 ORACLE_KIND = {0: 0, 1: 1, 2: 2}
 
 
-def run_pair(gas, ob, kind, chain, n, frames, blocks, channel_count=1, seed=0, dirs=64, redraw_every=2, ring=0, hrir=None, params_hook=None):
+def run_pair(gas, ob, kind, chain, n, frames, blocks, channel_count=1, seed=0, dirs=64, redraw_every=2, ring=0, hrir=None, params_hook=None, flags=0, draining_every=0):
     from godot_audio_spatializer_amd import synth
 
     rng = np.random.default_rng(seed)
     C = channel_count if kind == gas.capi.KIND_3D_MIX else 1
-    ctx = gas.SpatializerContext(max_sources=n + 8, frames=frames, channel_count=channel_count, er_ring_frames=ring)
+    ctx = gas.SpatializerContext(max_sources=n + 8, frames=frames, channel_count=channel_count, er_ring_frames=ring, flags=flags)
     if hrir is not None:
         ctx.hrtf_load(hrir)
     slots = ctx.source_alloc_many(n, kind, chain)
-    ora = ob.BatchOracle(kind, n, frames, channel_count=channel_count, chain=chain, hrir=hrir, er_ring_frames=max(ring, 1))
+    ora = ob.BatchOracle(kind, n, frames, channel_count=channel_count, chain=chain, hrir=hrir, er_ring_frames=max(ring, 1), crossfade=bool(flags & gas.capi.FLAG_HRTF_CROSSFADE))
+    exact = np.ones(n, bool)
+    if flags & gas.capi.FLAG_PEAKS_DRAINING_ONLY:
+        exact[:] = False
+        if draining_every:
+            exact[::draining_every] = True
+            for s_ in slots[exact]:
+                ctx.source_set_draining(s_, True)
     worst = 0.0
     for b in range(blocks):
         if b % redraw_every == 0:
@@ -40,7 +47,8 @@ def run_pair(gas, ob, kind, chain, n, frames, blocks, channel_count=1, seed=0, d
             assert e <= TOL, f"block {b} channel {c}: rel rms {e}"
         for c in range(C, channel_count):
             assert not mix[c].any()
-        np.testing.assert_allclose(peaks, rpeaks, rtol=2e-5, atol=1e-7)
+        np.testing.assert_allclose(peaks[exact], rpeaks[exact], rtol=2e-5, atol=1e-7)
+        assert np.all(np.isposinf(peaks[~exact]))
     ctx.close()
     return worst
 
@@ -142,3 +150,17 @@ def test_hrtf_frequency_domain_path(gas, ob, frames, chain, ring):
         np.testing.assert_allclose(peaks[draining], rpeaks[draining], rtol=2e-5, atol=1e-7)
         assert np.all(np.isposinf(peaks[~draining]))
     ctx.close()
+
+
+@pytest.mark.parametrize("mode", ["exact_peaks", "frequency_domain", "er_chain"])
+@pytest.mark.parametrize("frames", [512, 256])
+def test_hrtf_direction_crossfade(gas, ob, mode, frames):
+    """SURVEY.md 8f#4 (GAS_FLAG_HRTF_CROSSFADE): directions are redrawn every 2 callbacks, so half the callbacks
+    cross-fade every source's HRIR pair and the other half take the unchanged-direction path."""
+    from godot_audio_spatializer_amd import synth
+
+    K = gas.capi
+    hrir = synth.synthetic_hrir(np.random.default_rng(7), dirs=64)
+    flags = K.FLAG_HRTF_CROSSFADE | (K.FLAG_PEAKS_DRAINING_ONLY if mode == "frequency_domain" else 0)
+    chain = (K.FX_EARLY_REFLECTIONS, K.FX_HRTF) if mode == "er_chain" else (K.FX_HRTF,)
+    run_pair(gas, ob, K.KIND_EFFECT, chain, 150, frames, 8, hrir=hrir, flags=flags, draining_every=9, ring=4096 if mode == "er_chain" else 0)

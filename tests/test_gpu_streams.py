@@ -18,7 +18,7 @@ def to_float_stereo(pcm):
     return np.stack([f, f], axis=1) if pcm.ndim == 1 else f
 
 
-@pytest.mark.parametrize("kind_name", ["effect_copy", "mix_channel", "hrtf"])
+@pytest.mark.parametrize("kind_name", ["effect_copy", "mix_channel", "hrtf", "hrtf_crossfade"])
 def test_streams_match_oracle_mixer(gas, ob, kind_name):
     from godot_audio_spatializer_amd import synth
 
@@ -34,9 +34,11 @@ def test_streams_match_oracle_mixer(gas, ob, kind_name):
         "effect_copy": (K.KIND_EFFECT, ob.KIND_EFFECT, (), (), None),
         "mix_channel": (K.KIND_3D_MIX, ob.KIND_3D_MIX, (), (), None),
         "hrtf": (K.KIND_EFFECT, ob.KIND_EFFECT, (K.FX_HRTF,), (ob.FX_HRTF,), synth.synthetic_hrir(np.random.default_rng(7), dirs=8)),
+        "hrtf_crossfade": (K.KIND_EFFECT, ob.KIND_EFFECT, (K.FX_HRTF,), (ob.FX_HRTF,), synth.synthetic_hrir(np.random.default_rng(7), dirs=8)),
     }[kind_name]
+    xf = kind_name == "hrtf_crossfade"
     params = synth.draw_params(rng, n, dirs=8)
-    with gas.SpatializerContext(max_sources=n, frames=F, flags=K.FLAG_PEAKS_DRAINING_ONLY) as ctx:
+    with gas.SpatializerContext(max_sources=n, frames=F, flags=K.FLAG_PEAKS_DRAINING_ONLY | (K.FLAG_HRTF_CROSSFADE if xf else 0)) as ctx:
         if hrir is not None:
             ctx.hrtf_load(hrir)
         slots = ctx.source_alloc_many(n, kind, chain)
@@ -44,10 +46,16 @@ def test_streams_match_oracle_mixer(gas, ob, kind_name):
         for s, p in zip(slots, pcms):
             ctx.source_bind_stream(s, ctx.stream_create(p))
         rig = Rig(ob, okind, floats, F, chain=ochain, hrir=hrir)
+        if xf:
+            rig.hrtf.crossfade = 1
         rig.params[:] = params.astype(ob.PARAMS_DTYPE)
         active = np.ones(n, bool)
         thr = 1e-4  # db_to_linear(-80 dB), audio_spatializer.cpp:465
         for cb in range(30):
+            if xf and cb % 2 == 1:  # move every source: the next callback cross-fades
+                params["hrtf_dir"] = (params["hrtf_dir"] + 1 + cb) % 8
+                ctx.params_publish_batch(slots, params)
+                rig.params[:] = params.astype(ob.PARAMS_DTYPE)
             live = slots[active]
             got, peaks, hf = ctx.process_block_streams(live)
             rc, want = rig.get_mixed_frames(0)
@@ -61,7 +69,7 @@ def test_streams_match_oracle_mixer(gas, ob, kind_name):
                     if peaks[j].max() <= thr:
                         active[i] = False
                 else:
-                    assert np.all(np.isposinf(peaks[j])) or kind_name != "hrtf"
+                    assert np.all(np.isposinf(peaks[j])) or not kind_name.startswith("hrtf")
             for i in range(n):
                 assert active[i] == bool(rig.pbs[i].active), (cb, i)
             if not active.any():

@@ -233,3 +233,29 @@ def test_early_reflections_closed_form(ob):
     for g, d in zip(p["er_gain"][0], (int(v) for v in p["er_delay"][0])):
         ref[d:] += np.float64(g) * xs[:-d]
     assert rel_rms(y, ref) < 3e-7
+
+
+def test_hrtf_crossfade_closed_form(ob):
+    """8f#4: when the direction changes, out = t * (x * h_new) + (1 - t) * (x * h_old), t = i / F, over hist ++ x."""
+    F, rng = 256, np.random.default_rng(11)
+    hrir = (rng.standard_normal((3, 2, 256)) * np.exp(-np.arange(256) / 32)).astype(np.float32)
+    ora = ob.BatchOracle(ob.KIND_EFFECT, 1, F, chain=[ob.FX_HRTF], hrir=hrir, crossfade=True)
+    p = params(ob, 1, hrtf_gain=1.0)
+    dirs = [0, 0, 2, 1, 1]
+    x = rng.uniform(-0.5, 0.5, (5, 1, F, 2)).astype(np.float32)
+    outs = []
+    for b, d in enumerate(dirs):
+        p["hrtf_dir"] = d
+        outs.append(ora.block(p, x[b])[0][0])
+    mono = ((x[:, 0, :, 0] + x[:, 0, :, 1]) * np.float32(0.5)).reshape(-1)
+    g = np.ones(5 * F, np.float32)
+    g[:F] = np.arange(F, dtype=np.float32) / np.float32(F)
+    xs = (mono * g).astype(np.float64)
+    full = {d: [np.convolve(xs, hrir[d, ear].astype(np.float64))[: 5 * F] for ear in range(2)] for d in set(dirs)}
+    t = (np.arange(F, dtype=np.float32) / np.float32(F)).astype(np.float64)
+    for b, d in enumerate(dirs):
+        prev = dirs[b - 1] if b else d
+        sl = slice(b * F, (b + 1) * F)
+        for ear in range(2):
+            want = full[d][ear][sl] if prev == d else t * full[d][ear][sl] + (1 - t) * full[prev][ear][sl]
+            assert rel_rms(outs[b][:, ear], want) < 5e-7, (b, ear)
