@@ -520,7 +520,7 @@ __device__ __forceinline__ void hrtf_body(float2 *lds_all, const uint32_t wg, co
 			const uint32_t er_pos = st.er_pos[m.slot];
 			gas_audio_frame *ring = st.er_ring + (size_t)m.slot * er_R;
 			float *xs = reinterpret_cast<float *>(lds);
-#pragma unroll 1
+#pragma unroll 2 // 16 tap loads in flight per trip (4 spills, 1 serialises four round trips per source)
 			for (int q = 0; q < FQ; q++) {
 				const int f = lane + 64 * q;
 				gas_audio_frame fr = srow[f];
