@@ -106,6 +106,10 @@ struct gas_ctx {
 	float *d_fade_env = nullptr; // [64]
 	uint32_t *d_stream_slots = nullptr; // callback slot list in row order
 	std::vector<uint32_t> stream_slots_host; // what d_stream_slots / the cached launch groups currently hold
+	// parameter rows published from device memory for the cached slot list (row order), not yet in the table
+	const gas_params *pending_params = nullptr;
+	uint32_t pending_n = 0;
+	const gas_params *fresh_for_launch = nullptr; // set for the duration of one run_groups
 	bool fused_streams = false; // this callback's HRTF launch samples the bound streams itself (no materialised rows)
 	struct StreamRow { // compact mirror of the cached list's cursors: the per-callback host loop touches only this
 		uint64_t remaining = 0;
@@ -343,7 +347,7 @@ int run_groups(gas_ctx *c, const gas_audio_frame *d_src, const uint32_t *d_slots
 					g_pk.slots = nullptr;
 					g_pk.slot_base = groups[fd_gt + 1].slot_base;
 				}
-				e = gas_launch_hrtf_ols(c->stream, fd_gt == G_FX_ER_HRTF, (c->cfg.flags & GAS_FLAG_HRTF_CROSSFADE) != 0, g_fd, g_pk, c->st, c->tab, c->d_tw, F, c->hist_len, c->cfg.er_ring_frames, c->d_partials, p_off, fd_gt == G_FX_HRTF && c->fused_streams ? c->d_cursors : nullptr, c->d_fade_env);
+				e = gas_launch_hrtf_ols(c->stream, fd_gt == G_FX_ER_HRTF, (c->cfg.flags & GAS_FLAG_HRTF_CROSSFADE) != 0, g_fd, g_pk, c->st, c->tab, c->d_tw, F, c->hist_len, c->cfg.er_ring_frames, c->d_partials, p_off, fd_gt == G_FX_HRTF && c->fused_streams ? c->d_cursors : nullptr, c->d_fade_env, fd_gt == G_FX_HRTF ? c->fresh_for_launch : nullptr);
 			} break;
 			case G_FX_ER:
 				e = gas_launch_er_only(c->stream, ga, c->st, F, c->cfg.er_ring_frames, c->d_partials, p_off, c->partial_rows);
@@ -368,6 +372,17 @@ int run_groups(gas_ctx *c, const gas_audio_frame *d_src, const uint32_t *d_slots
 	if (channel_count > 1) {
 		GAS_HIP(c, gas_launch_mix_reduce(c->stream, c->d_partials + (size_t)c->partial_rows * F * 2, p_mix, c->partial_rows, channel_count - 1, F, d_out + F));
 	}
+	return GAS_OK;
+}
+
+// Scatter a deferred device-side publish into the table (list unchanged since it was recorded).
+int flush_pending_params(gas_ctx *c) {
+	if (!c->pending_params) {
+		return GAS_OK;
+	}
+	const gas_params *p = c->pending_params;
+	c->pending_params = nullptr;
+	GAS_HIP(c, gas_launch_scatter_params(c->stream, c->st.params, p, c->cached_identity_rows ? c->d_slots : c->d_slots_rows, c->pending_n));
 	return GAS_OK;
 }
 
@@ -832,6 +847,10 @@ int gas_params_publish_batch(gas_ctx *c, const uint32_t *slots, const gas_params
 	// slots == NULL addresses the slot list of the last gas_process_block, in its row order.
 	GAS_HIP(c, hipSetDevice(c->cfg.device));
 	if (slots) {
+		int rcp = flush_pending_params(c);
+		if (rcp != GAS_OK) {
+			return rcp;
+		}
 		if (n > c->cfg.max_sources) {
 			return GAS_ERR_INVALID_ARGUMENT;
 		}
@@ -849,7 +868,14 @@ int gas_params_publish_batch(gas_ctx *c, const uint32_t *slots, const gas_params
 		if (c->cached_n != n) {
 			return GAS_ERR_INVALID_ARGUMENT;
 		}
-		GAS_HIP(c, gas_launch_scatter_params(c->stream, c->st.params, params, c->cached_identity_rows ? c->d_slots : c->d_slots_rows, n));
+		// Deferred: the next gas_process_block over this same list consumes the rows in its own launch when it can
+		// (all sources plain HRTF), else scatters them first.  The buffer must stay untouched until then.
+		int rcp = flush_pending_params(c);
+		if (rcp != GAS_OK) {
+			return rcp;
+		}
+		c->pending_params = params;
+		c->pending_n = n;
 	}
 	return GAS_OK;
 }
@@ -879,6 +905,12 @@ int gas_calc_spatialization(gas_ctx *c, const gas_spatializer3d_config *cfgs, ui
 	}
 	std::lock_guard<std::mutex> lk(c->calc_mu);
 	GAS_HIP(c, hipSetDevice(c->cfg.device));
+	{
+		int rcp = flush_pending_params(c);
+		if (rcp != GAS_OK) {
+			return rcp;
+		}
+	}
 	GAS_HIP(c, hipMemcpyAsync(c->d_calc_cfgs, cfgs, sizeof(gas_spatializer3d_config) * n_cfgs, hipMemcpyHostToDevice, c->stream));
 	if (n_listeners) {
 		GAS_HIP(c, hipMemcpyAsync(c->d_calc_listeners, listeners, sizeof(gas_listener) * n_listeners, hipMemcpyHostToDevice, c->stream));
@@ -1183,6 +1215,12 @@ int gas_process_block(gas_ctx *c, const gas_audio_frame *src, const uint32_t *sl
 	if (hipSetDevice(c->cfg.device) != hipSuccess) {
 		return fail(GAS_ERR_NO_DEVICE);
 	}
+	if (c->pending_params && (slots || n == 0 || c->cached_n != n || !c->pending_free.empty())) {
+		rc = flush_pending_params(c); // the list may change: scatter with the mapping it was published for
+		if (rc != GAS_OK) {
+			return fail(rc);
+		}
+	}
 	apply_pending_frees(c);
 	if (slots || n == 0) { // an empty callback needs no list
 		rc = build_groups(c, slots, n);
@@ -1228,7 +1266,23 @@ int gas_process_block(gas_ctx *c, const gas_audio_frame *src, const uint32_t *sl
 		d_out = c->d_out;
 		d_peaks = c->d_peaks;
 	}
+	if (c->pending_params) {
+		bool only_hrtf = true;
+		for (int gt = 0; gt < G_COUNT; gt++) {
+			only_hrtf = only_hrtf && (gt == G_FX_HRTF || gt == G_FX_HRTF_PK || c->groups[gt].count == 0);
+		}
+		if (only_hrtf && c->pending_n == n) {
+			c->fresh_for_launch = c->pending_params; // k_hrtf_ols reads the rows and writes them through
+			c->pending_params = nullptr;
+		} else {
+			rc = flush_pending_params(c);
+			if (rc != GAS_OK) {
+				return fail(rc);
+			}
+		}
+	}
 	rc = run_groups(c, d_src, c->d_slots, c->cached_identity_rows ? nullptr : c->d_rows, c->groups, n, d_out, d_peaks, 0, C, -1);
+	c->fresh_for_launch = nullptr;
 	if (rc != GAS_OK) {
 		return fail(rc);
 	}
@@ -1290,7 +1344,10 @@ static int process_one(gas_ctx *c, uint32_t slot, int channel, bool mix_channel,
 	if ((gt == G_FX_HRTF_PK || gt == G_FX_ER_HRTF_PK) && c->tab.spec == nullptr) {
 		return GAS_ERR_NO_HRTF;
 	}
-	int rc = flush_params(c);
+	int rc = flush_pending_params(c);
+	if (rc == GAS_OK) {
+		rc = flush_params(c);
+	}
 	if (rc != GAS_OK) {
 		return rc;
 	}

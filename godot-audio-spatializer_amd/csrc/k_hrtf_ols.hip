@@ -405,7 +405,7 @@ struct HrtfLds {
 };
 
 template <int SQ, bool WITH_ER, bool PEAKS, bool SRC_PCM, bool XFADE>
-__device__ __forceinline__ void hrtf_body(float2 *lds_all, const uint32_t wg, const gas_group_args &g, const gas_dev_state &st, const gas_hrtf_table &tab, const float2 *__restrict__ tw, uint32_t spw, uint32_t er_R, float *__restrict__ my_partial, gas_cursor *__restrict__ cursors, const float *__restrict__ fade_env) {
+__device__ __forceinline__ void hrtf_body(float2 *lds_all, const uint32_t wg, const gas_group_args &g, const gas_dev_state &st, const gas_hrtf_table &tab, const float2 *__restrict__ tw, uint32_t spw, uint32_t er_R, float *__restrict__ my_partial, gas_cursor *__restrict__ cursors, const float *__restrict__ fade_env, const gas_params *__restrict__ fresh) {
 	static_assert(!(WITH_ER && SRC_PCM), "the early-reflection prologue reads float rows");
 	constexpr int FQ = 2 * SQ; // F / 64
 	constexpr int HQ = 8 - SQ; // hist_len / 64
@@ -472,7 +472,17 @@ __device__ __forceinline__ void hrtf_body(float2 *lds_all, const uint32_t wg, co
 		m.row = (uint32_t)__builtin_amdgcn_readlane((int)lm.row, 0);
 	}
 	if (have) {
-		const gas_params *P = st.params + lm.slot;
+		// `fresh`: parameter rows published from device memory for exactly this callback's list (row order) and not
+		// yet scattered: consume them here and write them through to the slot table (saves the scatter launch).
+		const gas_params *P = fresh ? fresh + lm.row : st.params + lm.slot;
+		if (fresh) {
+			const float4 *src4 = reinterpret_cast<const float4 *>(P);
+			float4 *dst4 = reinterpret_cast<float4 *>(st.params + lm.slot);
+#pragma unroll
+			for (int k = 0; k < 8; k++) {
+				dst4[k] = src4[k];
+			}
+		}
 		const float2 gd = *reinterpret_cast<const float2 *>(&P->hrtf_gain); // hrtf_gain, hrtf_dir: one 8-byte load
 		lm.g0 = st.hrtf_prev_gain[lm.slot];
 		lm.g1 = gd.x;
@@ -786,14 +796,14 @@ __device__ __forceinline__ void hrtf_body(float2 *lds_all, const uint32_t wg, co
 // One launch per callback for every HRTF source: workgroups [0, wgs_fd) run the frequency-domain body over
 // g_fd, the rest run the exact-peak body over g_pk (the draining playbacks).
 template <int SQ, bool WITH_ER, bool SRC_PCM, bool XFADE>
-__global__ __launch_bounds__(WAVES * 64, GAS_HRTF_WAVES_PER_SIMD) void k_hrtf_ols(gas_group_args g_fd, gas_group_args g_pk, uint32_t wgs_fd, gas_dev_state st, gas_hrtf_table tab, const float2 *__restrict__ tw, uint32_t spw_fd, uint32_t spw_pk, uint32_t er_R, float *__restrict__ partials, uint32_t p_offset, gas_cursor *__restrict__ cursors, const float *__restrict__ fade_env) {
+__global__ __launch_bounds__(WAVES * 64, GAS_HRTF_WAVES_PER_SIMD) void k_hrtf_ols(gas_group_args g_fd, gas_group_args g_pk, uint32_t wgs_fd, gas_dev_state st, gas_hrtf_table tab, const float2 *__restrict__ tw, uint32_t spw_fd, uint32_t spw_pk, uint32_t er_R, float *__restrict__ partials, uint32_t p_offset, gas_cursor *__restrict__ cursors, const float *__restrict__ fade_env, const gas_params *__restrict__ fresh) {
 	constexpr int LDS_F2 = HrtfLds<SQ, false>::TOTAL_F2 > HrtfLds<SQ, true>::TOTAL_F2 ? HrtfLds<SQ, false>::TOTAL_F2 : HrtfLds<SQ, true>::TOTAL_F2;
 	__shared__ float2 lds_all[LDS_F2];
 	float *my_partial = partials + ((size_t)p_offset + blockIdx.x) * (size_t)(2 * SQ * 64 * 2);
 	if (blockIdx.x < wgs_fd) {
-		hrtf_body<SQ, WITH_ER, false, SRC_PCM, XFADE>(lds_all, blockIdx.x, g_fd, st, tab, tw, spw_fd, er_R, my_partial, cursors, fade_env);
+		hrtf_body<SQ, WITH_ER, false, SRC_PCM, XFADE>(lds_all, blockIdx.x, g_fd, st, tab, tw, spw_fd, er_R, my_partial, cursors, fade_env, fresh);
 	} else {
-		hrtf_body<SQ, WITH_ER, true, SRC_PCM, XFADE>(lds_all, blockIdx.x - wgs_fd, g_pk, st, tab, tw, spw_pk, er_R, my_partial, cursors, fade_env);
+		hrtf_body<SQ, WITH_ER, true, SRC_PCM, XFADE>(lds_all, blockIdx.x - wgs_fd, g_pk, st, tab, tw, spw_pk, er_R, my_partial, cursors, fade_env, fresh);
 	}
 }
 
@@ -952,11 +962,11 @@ uint32_t gas_hrtf_partials(uint32_t n, uint32_t *sources_per_wave) {
 	return p.wgs_fd;
 }
 
-hipError_t gas_launch_hrtf_ols(hipStream_t stream, bool with_er, bool crossfade, const gas_group_args &g_fd, const gas_group_args &g_pk, const gas_dev_state &st, const gas_hrtf_table &tab, const float2 *twiddles, uint32_t frames, uint32_t hist_len, uint32_t er_ring_frames, float *partials, uint32_t p_offset, gas_cursor *cursors, const float *fade_env) {
+hipError_t gas_launch_hrtf_ols(hipStream_t stream, bool with_er, bool crossfade, const gas_group_args &g_fd, const gas_group_args &g_pk, const gas_dev_state &st, const gas_hrtf_table &tab, const float2 *twiddles, uint32_t frames, uint32_t hist_len, uint32_t er_ring_frames, float *partials, uint32_t p_offset, gas_cursor *cursors, const float *fade_env, const gas_params *fresh) {
 	if (g_fd.n + g_pk.n == 0) {
 		return hipSuccess;
 	}
-	if (frames % 128 != 0 || frames > 512 || hist_len != 512 - frames / 2 || (with_er && cursors)) {
+	if (frames % 128 != 0 || frames > 512 || hist_len != 512 - frames / 2 || (with_er && (cursors || fresh))) {
 		return hipErrorInvalidValue;
 	}
 	gas_hrtf_launch_plan plan;
@@ -964,7 +974,7 @@ hipError_t gas_launch_hrtf_ols(hipStream_t stream, bool with_er, bool crossfade,
 	const uint32_t wgs_fd = plan.wgs_fd, spw_fd = plan.spw_fd, spw_pk = plan.spw_pk;
 	dim3 grid(plan.wgs_fd + plan.wgs_pk), block(WAVES * 64);
 #define GAS_HRTF_LAUNCH(SQv, ERv, PCMv, XFv) \
-	hipLaunchKernelGGL((k_hrtf_ols<SQv, ERv, PCMv, XFv>), grid, block, 0, stream, g_fd, g_pk, wgs_fd, st, tab, twiddles, spw_fd, spw_pk, er_ring_frames, partials, p_offset, cursors, fade_env)
+	hipLaunchKernelGGL((k_hrtf_ols<SQv, ERv, PCMv, XFv>), grid, block, 0, stream, g_fd, g_pk, wgs_fd, st, tab, twiddles, spw_fd, spw_pk, er_ring_frames, partials, p_offset, cursors, fade_env, fresh)
 #define GAS_HRTF_CASE3(SQv, XFv)                      \
 	if (with_er) {                                    \
 		GAS_HRTF_LAUNCH(SQv, true, false, XFv);       \

@@ -154,6 +154,9 @@ int gas_source_set_draining(gas_ctx *ctx, uint32_t slot, int draining);
 /* ---- set_spatializer_parameters (audio_spatializer.cpp:558-564): latest wins,
  * snapshotted once at the start of the next gas_process_block (:328) ------ */
 int gas_params_publish(gas_ctx *ctx, uint32_t slot, const gas_params *params);
+/* params_mem == GAS_MEM_DEVICE with slots == NULL addresses the slot list of the last gas_process_block in its row
+ * order and is DEFERRED: the rows are read when the next gas_process_block (or any other entry that needs the table)
+ * is enqueued, so the buffer must stay valid and unmodified on other streams until then. */
 int gas_params_publish_batch(gas_ctx *ctx, const uint32_t *slots, const gas_params *params, uint32_t n, int params_mem);
 
 /* ---- NEW AudioSpatializerHRTF resource: hrir is [dirs][2 ears][taps] f32, taps <= 256 */

@@ -233,3 +233,50 @@ def test_device_memory_path_equals_host_memory_path(gas):
     for (m0, p0), (m1, p1) in zip(*res):
         np.testing.assert_array_equal(m0, m1)  # same kernels, same order: bitwise
         np.testing.assert_array_equal(p0, p1)
+
+
+@pytest.mark.parametrize("mixed", [False, True])
+def test_deferred_device_publish_equals_host_publish(gas, mixed):
+    """gas_params_publish_batch(GAS_MEM_DEVICE, slots=NULL) is deferred: consumed inside the HRTF launch when every
+    source is a plain HRTF chain, scattered first otherwise, and scattered with the OLD mapping when the slot list
+    changes before the next callback.  Results must equal host-published parameters bit for bit."""
+    import torch
+
+    from godot_audio_spatializer_amd import synth
+
+    K = gas.capi
+    n, F = 100, 512
+    hr = hrir8()
+    outs = {}
+    for how in ("host", "device"):
+        rng = np.random.default_rng(12)
+        with gas.SpatializerContext(max_sources=n + 4, frames=F, flags=K.FLAG_PEAKS_DRAINING_ONLY) as ctx:
+            ctx.hrtf_load(hr)
+            slots = list(ctx.source_alloc_many(n, K.KIND_EFFECT, (K.FX_HRTF,)))
+            if mixed:
+                slots += list(ctx.source_alloc_many(4, K.KIND_3D_MIX))
+            slots = np.array(slots, np.uint32)
+            m = len(slots)
+            ctx.source_set_draining(slots[5], True)
+            ctx.params_publish_batch(slots, synth.draw_params(rng, m, dirs=8))
+            res = []
+            keep = []
+            for b in range(6):
+                src = synth.draw_sources(rng, m, F)
+                use = slots
+                if b == 4:  # the list shrinks while a device publish is pending
+                    use, src = slots[:-3], src[:-3]
+                mix, peaks = ctx.process_block(src, use)
+                res.append((mix.copy(), peaks.copy()))
+                p = synth.draw_params(rng, m, dirs=8)
+                if how == "host" or b == 4:
+                    ctx.params_publish_batch(slots, p)
+                else:
+                    d = torch.from_numpy(p.view(np.uint8).reshape(m, 128).copy()).cuda()
+                    keep.append(d)  # must outlive the next callback
+                    torch.cuda.synchronize()
+                    ctx.params_publish_device(d.data_ptr(), m)
+            outs[how] = res
+    for (m0, p0), (m1, p1) in zip(outs["host"], outs["device"]):
+        np.testing.assert_array_equal(m0, m1)
+        np.testing.assert_array_equal(p0, p1)
