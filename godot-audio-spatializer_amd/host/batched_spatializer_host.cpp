@@ -294,6 +294,27 @@ int gas_host_playback_count(gas_host *h) {
 	return h ? (int)h->list.size() : 0;
 }
 
+void gas_host_bus_map(int should_mix_channels, int channel, const float bus_volume[GAS_MAX_CHANNELS_PER_BUS][2], const float mix_volumes[GAS_MAX_CHANNELS_PER_BUS][2], float out[GAS_MAX_CHANNELS_PER_BUS][2]) {
+	for (int c = 0; c < GAS_MAX_CHANNELS_PER_BUS; c++) {
+		if (should_mix_channels) { // audio_spatializer.cpp:295-313
+			float left = 0.0f, right = 0.0f;
+			if (c == channel) {
+				if (mix_volumes[c][0] > 0.0) {
+					left = bus_volume[c][0] / mix_volumes[c][0];
+				}
+				if (mix_volumes[c][1] > 0.0) {
+					right = bus_volume[c][1] / mix_volumes[c][1];
+				}
+			}
+			out[c][0] = left;
+			out[c][1] = right;
+		} else { // :314-318
+			out[c][0] = mix_volumes[c][0];
+			out[c][1] = mix_volumes[c][1];
+		}
+	}
+}
+
 int gas_host_get_mixed_frames(gas_host *h, int channel, gas_audio_frame *frames, int frame_count) {
 	if (!h || !frames || frame_count <= 0) {
 		return GAS_ERR_INVALID_ARGUMENT;

@@ -43,6 +43,12 @@ int gas_host_playback_count(gas_host *host); /* nodes still on the list */
  * ("Unexpected channel") or GAS_ERR_FRAME_COUNT ("Unexpected frame count"). */
 int gas_host_get_mixed_frames(gas_host *host, int channel, gas_audio_frame *frames, int frame_count);
 
+/* get_bus_map (audio_spatializer.cpp:274-324) for ONE bus: the per-channel-pair factors AudioServer multiplies the
+ * frames returned for channel `channel` by.  Mix-channel instances mixed their volumes in already, so only the
+ * requested pair is non-zero and the bus volume is normalised by the mix volume (0 where the mix volume is <= 0,
+ * :295-313); other instances pass the raw mix volumes through (:314-318).  bus_volume / mix_volumes / out: [4][2]. */
+void gas_host_bus_map(int should_mix_channels, int channel, const float bus_volume[GAS_MAX_CHANNELS_PER_BUS][2], const float mix_volumes[GAS_MAX_CHANNELS_PER_BUS][2], float out[GAS_MAX_CHANNELS_PER_BUS][2]);
+
 #ifdef __cplusplus
 }
 #endif

@@ -126,3 +126,22 @@ def test_c_example_runs_on_the_gpu(gas, tmp_path):
     out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "gas_process_block: ok" in out.stdout and "gas_host_get_mixed_frames: ok" in out.stdout
+
+
+def test_host_bus_map_matches_oracle(gas, ob):
+    """gas_host_bus_map (host arithmetic, no GPU) vs the oracle's restatement of get_bus_map (audio_spatializer.cpp:295-319)."""
+    lib = gas.load_library()
+    lib.gas_host_bus_map.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.gas_host_bus_map.restype = None
+    rng = np.random.default_rng(0)
+    for trial in range(50):
+        bus = rng.uniform(0, 1, (4, 2)).astype(np.float32)
+        mixv = rng.uniform(-0.2, 1, (4, 2)).astype(np.float32)
+        mixv[rng.integers(4), rng.integers(2)] = 0.0
+        for smc in (0, 1):
+            for ch in range(4):
+                got = np.full((4, 2), np.nan, np.float32)
+                want = np.full((4, 2), np.nan, np.float32)
+                lib.gas_host_bus_map(smc, ch, bus.ctypes.data, mixv.ctypes.data, got.ctypes.data)
+                ob.lib().gaso_bus_map(smc, ch, bus.ctypes.data, mixv.ctypes.data, want.ctypes.data)
+                np.testing.assert_array_equal(got, want)
