@@ -50,42 +50,73 @@ def pmc_traffic(kernel, workload, n_local, peaks):
     return best
 
 
-def cpu_baseline(kind, chain, frames, dirs, hrir, ring, budget_s=12.0):
-    """Reference-equivalent CPU path (oracle, scalar f32, 1 core) on a bounded sample of the workload."""
+def _cpu_worker(args):
+    """One worker of the all-cores baseline: its shard of the sources, `blocks` callbacks; returns seconds."""
+    kind, chain, frames, dirs, hrir, ring, n, blocks, seed = args
     from oracle import binding as ob
     from godot_audio_spatializer_amd import synth
 
-    rng = np.random.default_rng(1234)
-    n = 512 if 3 in chain else 2048
+    rng = np.random.default_rng(seed)
     ora = ob.BatchOracle(kind, n, frames, chain=chain, hrir=hrir, er_ring_frames=max(ring, 1), hrtf_impl=1)
     p = synth.draw_params(rng, n, dirs=dirs, ring_frames=max(ring, 2 * frames), frames=frames).astype(ob.PARAMS_DTYPE)
     src = synth.draw_sources(rng, n, frames)
     ora.block(p, src)  # warm-up (state, caches)
-    blocks = 0
     t0 = time.perf_counter()
-    while True:
-        if blocks % 2 == 0:
-            p = synth.draw_params(rng, n, dirs=dirs, ring_frames=max(ring, 2 * frames), frames=frames).astype(ob.PARAMS_DTYPE)
-        t_in = time.perf_counter()
-        ora.block(p, src)
-        blocks += 1
-        if time.perf_counter() - t0 > budget_s or blocks >= 64:
-            break
-    # time only the oracle calls: re-measure precisely over the same number of blocks
-    t1 = time.perf_counter()
     for _ in range(blocks):
         ora.block(p, src)
-    dt = time.perf_counter() - t1
-    return {
+    return time.perf_counter() - t0
+
+
+def cpu_baseline(kind, chain, frames, dirs, hrir, ring, budget_s=10.0):
+    """Reference-equivalent CPU path (oracle, scalar f32) on a bounded sample of the workload: 1 core (the faithful
+    figure: Godot mixes on one audio thread), plus the same sample sharded over every host core."""
+    n = 512 if 3 in chain else 2048
+    # size the sample to ~budget_s of single-core work
+    t_probe = _cpu_worker((kind, chain, frames, dirs, hrir, ring, n, 2, 1234)) / 2
+    blocks = int(max(4, min(256, budget_s / max(t_probe, 1e-6))))
+    dt = _cpu_worker((kind, chain, frames, dirs, hrir, ring, n, blocks, 1234))
+    out = {
         "value": n * frames * blocks / dt,
         "unit": "AudioFrames/s",
         "cores": 1,
         "kind": "port",
         "sample": f"{n} sources x {blocks} callbacks of the same workload, oracle scalar f32 path (HRTF by radix-2 overlap-save), 1 thread",
     }
+    try:
+        # all host cores: independent child processes of this script in --cpu-worker mode (they never touch the GPU),
+        # each on its shard of the sources, hard timeout so the headline line can never hang on them
+        import subprocess
+        import tempfile
+
+        cores = min(len(os.sched_getaffinity(0)), 16)  # a one-GPU box's CPU share, not every visible CPU
+        if cores > 1:
+            per = max(1, n // cores)
+            with tempfile.TemporaryDirectory() as td:
+                hp = os.path.join(td, "hrir.npy")
+                np.save(hp, hrir if hrir is not None else np.zeros((1, 2, 256), np.float32))
+                cmd = [sys.executable, os.path.abspath(__file__), "--cpu-worker", json.dumps([kind, list(chain), frames, dirs, hp if hrir is not None else "", ring, per, blocks])]
+                procs = [subprocess.Popen(cmd + [str(1234 + i)], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True) for i in range(cores)]
+                times = []
+                deadline = time.time() + 6 * budget_s + 60
+                for pr in procs:
+                    try:
+                        o, _ = pr.communicate(timeout=max(1.0, deadline - time.time()))
+                        times.append(float(o.strip().splitlines()[-1]))
+                    except Exception:
+                        pr.kill()
+                        raise
+            out["all_cores"] = {"value": per * cores * frames * blocks / max(times), "cores": cores, "sample": f"{per} sources per process x {cores} processes x {blocks} callbacks"}
+    except Exception as e:  # the extra figure must never cost the headline line
+        out["all_cores"] = {"error": repr(e)}
+    return out
 
 
 def main():
+    if len(sys.argv) >= 4 and sys.argv[1] == "--cpu-worker":  # child of cpu_baseline(): CPU only, prints seconds
+        kind, chain, frames, dirs, hp, ring, n, blocks = json.loads(sys.argv[2])
+        hrir = np.load(hp) if hp else None
+        print(_cpu_worker((kind, tuple(chain), frames, dirs, hrir, ring, n, blocks, int(sys.argv[3]))))
+        return
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
@@ -303,37 +334,43 @@ def main():
 
 
 def probe_max_sources(gas, synth, torch, kind, chain, frames, hrir, dirs):
-    """Largest N (from a fixed ladder) whose p99 callback time stays under 10 ms on one GPU."""
+    """Largest N (from a fixed ladder) whose p99 callback time stays under 10 ms on one GPU.  One context sized
+    for the top rung; each rung runs the first N slots."""
+    ladder = [1 << 20, 1 << 21, 3 << 20, 1 << 22, 5 << 20, 6 << 20, 7 << 20]
+    top = ladder[-1]
     best = None
-    ladder = [1 << 19, 1 << 20, 3 << 19, 1 << 21, 5 << 19, 3 << 20]
-    for n in ladder:
-        ctx = gas.SpatializerContext(max_sources=n, frames=frames, channel_count=1, flags=gas.capi.FLAG_PEAKS_DRAINING_ONLY)
-        try:
-            ctx.set_stream(torch.cuda.current_stream().cuda_stream)
-            ctx.hrtf_load(hrir)
-            slots = ctx.source_alloc_many(n, kind, chain)
-            rng = np.random.default_rng(99)
-            ctx.params_publish_batch(slots, synth.draw_params(rng, n, dirs=dirs, frames=frames))
-            src = torch.rand(n, frames, 2, device="cuda") - 0.5
-            out = torch.zeros(1, frames, 2, device="cuda")
-            peaks = torch.zeros(n, 2, device="cuda")
-            ctx.process_block_raw(src.data_ptr(), slots, n, frames, out.data_ptr(), peaks.data_ptr(), 1)
+    ctx = gas.SpatializerContext(max_sources=top, frames=frames, channel_count=1, flags=gas.capi.FLAG_PEAKS_DRAINING_ONLY)
+    try:
+        ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+        ctx.hrtf_load(hrir)
+        slots = ctx.source_alloc_many(top, kind, chain)
+        rng = np.random.default_rng(99)
+        chunk = 1 << 20
+        for a in range(0, top, chunk):  # publish in chunks: the host staging copy is 128 B per source
+            ctx.params_publish_batch(slots[a:a + chunk], synth.draw_params(rng, min(chunk, top - a), dirs=dirs, frames=frames))
+        src = torch.rand(top, frames, 2, device="cuda") - 0.5
+        out = torch.zeros(1, frames, 2, device="cuda")
+        peaks = torch.zeros(top, 2, device="cuda")
+        for n in ladder:
+            rc = ctx.process_block_raw(src.data_ptr(), slots[:n], n, frames, out.data_ptr(), peaks.data_ptr(), 1)
+            if rc != 0:
+                break
             torch.cuda.synchronize()
             times = []
-            for _ in range(24):
+            for _ in range(16):
                 t0 = time.perf_counter()
                 ctx.process_block_raw(src.data_ptr(), None, n, frames, out.data_ptr(), peaks.data_ptr(), 1)
                 torch.cuda.synchronize()
                 times.append(time.perf_counter() - t0)
-            p99 = float(np.sort(times[4:])[-1]) * 1e3
-            del src, out, peaks
-        finally:
-            ctx.close()
-            torch.cuda.empty_cache()
-        if p99 < 10.0:
-            best = {"sources": n, "p99_callback_ms": p99}
-        else:
-            break
+            p99 = float(np.sort(times[2:])[-1]) * 1e3
+            if p99 < 10.0:
+                best = {"sources": n, "p99_callback_ms": p99}
+            else:
+                break
+        del src, out, peaks
+    finally:
+        ctx.close()
+        torch.cuda.empty_cache()
     return best
 
 
