@@ -448,3 +448,61 @@ class BatchedSpatializerHost:
         out = np.full((frame_count, 2), np.nan, dtype=np.float32)
         rc = self.lib.gas_host_get_mixed_frames(self.h, channel, _np_ptr(out), frame_count)
         return rc, out
+
+
+class MultiContext:
+    """ctypes view of gas_multi_* (include/gas_amd_host.h): several per-device contexts in one process."""
+
+    def __init__(self, devices, max_sources, frames=512, channel_count=1, mix_rate=48000.0, er_ring_frames=0, flags=0):
+        L = self.lib = load_library()
+        vp, u32, i32 = C.c_void_p, C.c_uint32, C.c_int
+        L.gas_multi_create.argtypes = [C.POINTER(Config), C.POINTER(C.c_int32), u32, C.POINTER(vp)]
+        L.gas_multi_destroy.argtypes = [vp]
+        L.gas_multi_destroy.restype = None
+        L.gas_multi_shards.argtypes = [vp]
+        L.gas_multi_shards.restype = u32
+        L.gas_multi_shard.argtypes = [vp, u32]
+        L.gas_multi_shard.restype = vp
+        L.gas_multi_least_loaded.argtypes = [vp]
+        L.gas_multi_least_loaded.restype = u32
+        L.gas_multi_note_alloc.argtypes = [vp, u32, i32]
+        L.gas_multi_note_alloc.restype = None
+        L.gas_multi_process_block.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(u32), u32, vp, C.POINTER(vp)]
+        self.frames, self.channel_count = frames, channel_count
+        cfg = Config(C.sizeof(Config), 0, max_sources, frames, channel_count, mix_rate, er_ring_frames, flags)
+        dev = (C.c_int32 * len(devices))(*devices)
+        h = C.c_void_p()
+        rc = L.gas_multi_create(C.byref(cfg), dev, len(devices), C.byref(h))
+        if rc != 0:
+            raise GasError(rc, "gas_multi_create", L.gas_strerror(rc).decode())
+        self.h = h
+        self.shards = []
+        for g in range(len(devices)):
+            ctx = SpatializerContext.__new__(SpatializerContext)  # a view: the multi-context owns the handle
+            ctx.lib, ctx.frames, ctx.channel_count, ctx.max_sources = L, frames, channel_count, max_sources
+            ctx.h = C.c_void_p(L.gas_multi_shard(h, g))
+            ctx.close = lambda: None
+            self.shards.append(ctx)
+
+    def close(self):
+        if self.h:
+            for s in self.shards:
+                s.h = None
+            self.lib.gas_multi_destroy(self.h)
+            self.h = None
+
+    def process_block(self, src_per_shard, slots_per_shard):
+        G = len(self.shards)
+        srcs = [np.ascontiguousarray(s, dtype=np.float32) for s in src_per_shard]
+        sls = [np.ascontiguousarray(s, dtype=np.uint32) for s in slots_per_shard]
+        pks = [np.zeros((max(len(s), 1), 2), np.float32) for s in sls]
+        vp = C.c_void_p
+        a_src = (vp * G)(*[s.ctypes.data for s in srcs])
+        a_sl = (vp * G)(*[s.ctypes.data for s in sls])
+        a_pk = (vp * G)(*[p.ctypes.data for p in pks])
+        a_n = (C.c_uint32 * G)(*[len(s) for s in sls])
+        out = np.full((self.channel_count, self.frames, 2), np.nan, np.float32)
+        rc = self.lib.gas_multi_process_block(self.h, a_src, a_sl, a_n, self.frames, _np_ptr(out), a_pk)
+        if rc != 0:
+            raise GasError(rc, "gas_multi_process_block", self.lib.gas_strerror(rc).decode())
+        return out, [p[: len(s)] for p, s in zip(pks, sls)]

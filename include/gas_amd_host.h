@@ -43,6 +43,24 @@ int gas_host_playback_count(gas_host *host); /* nodes still on the list */
  * ("Unexpected channel") or GAS_ERR_FRAME_COUNT ("Unexpected frame count"). */
 int gas_host_get_mixed_frames(gas_host *host, int channel, gas_audio_frame *frames, int frame_count);
 
+/* ---- several GPUs in ONE process (the in-engine variant) ------------------------------------
+ * Sources shard by slot across `n_devices` contexts (one per listed HIP device; the same device may be listed more
+ * than once, which is how this is tested on a one-GPU box).  Every shard runs its own gas_process_block; each then
+ * writes its [C][F] partial mix into a root-resident [G][C][F] buffer over its own link (hipMemcpyPeerAsync) and the
+ * root adds the G partials in fixed shard order with the library's deterministic reduce -- the all-to-one pattern
+ * SURVEY.md 8e prefers over a ring for a 4 KiB, latency-bound message.  bench.py's one-process-per-GPU RCCL path is
+ * the other variant of the same sharding. */
+typedef struct gas_multi gas_multi;
+int gas_multi_create(const gas_config *cfg /* .device ignored */, const int32_t *devices, uint32_t n_devices, gas_multi **out);
+void gas_multi_destroy(gas_multi *m);
+uint32_t gas_multi_shards(gas_multi *m);
+gas_ctx *gas_multi_shard(gas_multi *m, uint32_t shard); /* the shard's context: sources, parameters, HRIRs are per shard */
+uint32_t gas_multi_least_loaded(gas_multi *m); /* shard with the fewest sources registered through gas_multi_note_alloc */
+void gas_multi_note_alloc(gas_multi *m, uint32_t shard, int delta); /* +1 after a gas_source_alloc on it, -1 after a free */
+/* One callback: src[g] is shard g's [n[g]][frames] host rows, slots[g] its slot list; out is the summed [C][frames] mix
+ * (host); peaks[g] (may be NULL) receives shard g's [n[g]][2] peaks.  Host memory only. */
+int gas_multi_process_block(gas_multi *m, const gas_audio_frame *const *src, const uint32_t *const *slots, const uint32_t *n, uint32_t frames, gas_audio_frame *out, float *const *peaks);
+
 /* get_bus_map (audio_spatializer.cpp:274-324) for ONE bus: the per-channel-pair factors AudioServer multiplies the
  * frames returned for channel `channel` by.  Mix-channel instances mixed their volumes in already, so only the
  * requested pair is non-zero and the bus volume is normalised by the mix volume (0 where the mix volume is <= 0,
