@@ -11,8 +11,8 @@
 //
 // Geometry (CDNA4, wave64): one 64-lane workgroup = 32 sources x 2 ears; every lane owns one
 // serial recurrence (the biquad is a dependent chain over the F frames).
-// The 4 KiB-strided source rows are staged through LDS in [32 sources x 16 frames] tiles with
-// coalesced 16-byte loads (8 lanes cover one 128-byte line of one row), double-buffered against the
+// The 4 KiB-strided source rows are staged through LDS in [32 sources x KF frames] tiles (KF = 32) with
+// coalesced 16-byte loads (16 lanes cover one 256-byte run of one row), double-buffered against the
 // recurrence.  After each tile the wave switches roles: lane (half, frame, ear) sums the tile's 32
 // outputs over sources in fixed order and lanes 0..31 store 128 contiguous bytes of this
 // workgroup's partial mix.  No atomics in the sum: k_mix_reduce adds the partials in fixed order.
@@ -24,8 +24,17 @@
 namespace {
 
 constexpr int SRC_PER_WG = 32;
-constexpr int KF = 16; // frames per staged tile
-constexpr int ROW = 34; // LDS row stride in floats: 32 + 2 pad -> (34*sl + ear) % 32 distinct over a half-wave
+#ifndef GAS_BIQUAD_KF
+#define GAS_BIQUAD_KF 32
+#endif
+constexpr int KF = GAS_BIQUAD_KF; // frames per staged tile (16 or 32): the per-tile overhead (staging, two barriers, role-switch sum) is paid
+                                  // once per KF recurrence steps; measured: 32 is 9 % faster at N = 256 (cfg2), 16 is 4 % faster at N = 65 536
+constexpr int COLS = KF * 2; // floats per source per tile
+constexpr int ROW = COLS + 2; // LDS row stride in floats: + 2 pad -> (ROW*sl + ear) % 32 = (2 sl + ear) % 32, distinct over a half-wave
+constexpr int PARTS = COLS / 4; // 16-byte pieces per source row per tile
+constexpr int LOADS = SRC_PER_WG * PARTS / 64; // staging loads per lane per tile
+constexpr int GROUPS = 64 / COLS; // lane groups of the role-switch sum (2 at KF = 16, 1 at KF = 32)
+static_assert(KF == 16 || KF == 32, "tile size");
 
 struct Coeffs {
 	float b0, b1, b2, a1, a2;
@@ -74,7 +83,7 @@ struct LaneState {
 // The tile loop, specialised on the two wave-uniform conditions so neither the IEEE division of the
 // non-power-of-two lerp nor the bypass-branch selects are evaluated per step.
 template <int MODE, bool F_POW2, bool ALL_FILT>
-__device__ __forceinline__ void run_tiles(LaneState &L, float (&tile)[2][SRC_PER_WG * ROW], const float *const (&ld_base)[4], uint32_t F, float *__restrict__ my_partial, int lane, int sl, int ear) {
+__device__ __forceinline__ void run_tiles(LaneState &L, float (&tile)[2][SRC_PER_WG * ROW], const float *const (&ld_base)[LOADS], uint32_t F, float *__restrict__ my_partial, int lane, int sl, int ear) {
 	Coeffs co = L.co, inc = L.inc;
 	float ha1 = L.ha1, ha2 = L.ha2, hb1 = L.hb1, hb2 = L.hb2;
 	const float vs = L.vs, vf = L.vf;
@@ -85,9 +94,9 @@ __device__ __forceinline__ void run_tiles(LaneState &L, float (&tile)[2][SRC_PER
 	const float Ff = (float)(int)F;
 	const float invF = 1.0f / Ff;
 	const uint32_t n_tiles = F / KF;
-	float4 pre[4];
+	float4 pre[LOADS];
 #pragma unroll
-	for (int q = 0; q < 4; q++) {
+	for (int q = 0; q < LOADS; q++) {
 		pre[q] = *reinterpret_cast<const float4 *>(ld_base[q]);
 	}
 
@@ -95,15 +104,15 @@ __device__ __forceinline__ void run_tiles(LaneState &L, float (&tile)[2][SRC_PER
 		float *tb = tile[tl & 1];
 		// registers -> LDS (two 8-byte stores; rows are 136 B so 16-byte stores would misalign)
 #pragma unroll
-		for (int q = 0; q < 4; q++) {
+		for (int q = 0; q < LOADS; q++) {
 			int idx = q * 64 + lane;
-			float *d = tb + (idx >> 3) * ROW + (idx & 7) * 4;
+			float *d = tb + (idx / PARTS) * ROW + (idx % PARTS) * 4;
 			*reinterpret_cast<float2 *>(d) = make_float2(pre[q].x, pre[q].y);
 			*reinterpret_cast<float2 *>(d + 2) = make_float2(pre[q].z, pre[q].w);
 		}
 		if (tl + 1 < n_tiles) {
 #pragma unroll
-			for (int q = 0; q < 4; q++) {
+			for (int q = 0; q < LOADS; q++) {
 				pre[q] = *reinterpret_cast<const float4 *>(ld_base[q] + (size_t)(tl + 1) * KF * 2);
 			}
 		}
@@ -165,18 +174,23 @@ __device__ __forceinline__ void run_tiles(LaneState &L, float (&tile)[2][SRC_PER
 		}
 		__syncthreads();
 
-		// role switch: lane (h, j) sums column j = frame*2+ear over sources 16h .. 16h+15, in order
+		// role switch: lane (h, j) sums column j = frame*2+ear over its group's sources, in order; the groups
+		// (two at KF = 16) are then added in order too
 		{
-			const int h = lane >> 5, j = lane & 31;
-			const float *col = tb + (16 * h) * ROW + j;
+			const int h = lane / COLS, j = lane % COLS;
+			constexpr int PER = SRC_PER_WG / GROUPS;
+			const float *col = tb + (PER * h) * ROW + j;
 			float s = 0.0f;
 #pragma unroll
-			for (int k = 0; k < 16; k++) {
+			for (int k = 0; k < PER; k++) {
 				s += col[k * ROW];
 			}
-			const float s_hi = __shfl_down(s, 32);
-			if (lane < 32) {
-				my_partial[(size_t)tl * (KF * 2) + j] = s + s_hi;
+			if constexpr (GROUPS == 2) {
+				const float s_hi = __shfl_down(s, 32);
+				s += s_hi;
+			}
+			if (lane < COLS) {
+				my_partial[(size_t)tl * COLS + j] = s;
 			}
 		}
 		// the next iteration writes the other buffer; this one is rewritten two tiles later,
@@ -206,16 +220,16 @@ __global__ __launch_bounds__(64) void k_biquad_mix(gas_group_args g, gas_dev_sta
 	const uint32_t row = g.rows ? g.rows[ec] : ec;
 	const gas_params *P = st.params + slot;
 
-	// Row base of each of this lane's 4 staging loads per tile: load q covers tile element
-	// idx = q*64 + lane -> source idx>>3, 16-byte part idx&7.
-	const float *ld_base[4];
+	// Row base of each of this lane's staging loads per tile: load q covers tile element
+	// idx = q*64 + lane -> source idx / PARTS, 16-byte part idx % PARTS.
+	const float *ld_base[LOADS];
 #pragma unroll
-	for (int q = 0; q < 4; q++) {
+	for (int q = 0; q < LOADS; q++) {
 		int idx = q * 64 + lane;
-		uint32_t le = blockIdx.x * SRC_PER_WG + (idx >> 3);
+		uint32_t le = blockIdx.x * SRC_PER_WG + (idx / PARTS);
 		le = le < g.n ? le : g.n - 1;
 		uint32_t lrow = g.rows ? g.rows[le] : le;
-		ld_base[q] = reinterpret_cast<const float *>(g.src) + (size_t)lrow * F * 2 + (idx & 7) * 4;
+		ld_base[q] = reinterpret_cast<const float *>(g.src) + (size_t)lrow * F * 2 + (idx % PARTS) * 4;
 	}
 
 	// ---- per-lane DSP state (SpatializerPlaybackData3D, audio_spatializer_3d.h:85-99) ----
