@@ -1,9 +1,11 @@
-"""An independent float64 twin of the reference's time-varying biquad path, written from the prose of SURVEY.md
-Appendix A (items 8-10) and Appendix B -- plain Python loops, no code shared with oracle/gas_oracle.c -- and
-compared with the C oracle (f32, op-for-op) over several callbacks with changing parameters.  The two differ only by
-f32 rounding -- dominated by the 512 in-place `coeffs += incr` steps per block, which in f32 drift ~1e-5 from the
-float64 ramp -- so they must agree to 1e-4 relative; a semantic slip (ramp start, history clear, lerp form, which
-pair feeds prev_mix_volume, stored-negated feedback terms) would show up as a gross mismatch."""
+"""An independent twin of the reference's time-varying biquad path, written from the prose of SURVEY.md Appendix A
+(items 8-10) and Appendix B -- plain Python loops over numpy float32 scalars, no code shared with
+oracle/gas_oracle.c -- and compared with the C oracle over several callbacks with changing parameters.
+The twin rounds to f32 where the reference does (members are float; coefficients are computed in double, stored as
+float, then normalised), so the two must agree to ~1e-6; a float64 twin is NOT a usable check here: the 512 in-place
+`coeffs += incr` steps per block drift ~3e-5 in f32 and, with the poles near the unit circle at small shelf gains,
+that alone moves the output by ~1e-3.  A semantic slip (ramp start, history clear, lerp form, which pair feeds
+prev_mix_volume, stored-negated feedback terms) shows up as a gross mismatch either way."""
 import math
 
 import numpy as np
@@ -20,26 +22,30 @@ def highshelf64(sr, cutoff, gain):
     beta = math.sqrt(A) / 1.0
     cw, sw = math.cos(w), math.sin(w)
     a0 = (A + 1) - (A - 1) * cw + beta * sw
-    b0 = A * ((A + 1) + (A - 1) * cw + beta * sw) / a0
-    b1 = -2 * A * ((A - 1) + (A + 1) * cw) / a0
-    b2 = A * ((A + 1) + (A - 1) * cw - beta * sw) / a0
-    a1 = 2 * ((A - 1) - (A + 1) * cw) / -a0
-    a2 = ((A + 1) - (A - 1) * cw - beta * sw) / -a0
+    f = np.float32
+    # members are float: the numerators are stored (rounded) before the division by a0 rounds again
+    b0 = f(float(f(A * ((A + 1) + (A - 1) * cw + beta * sw))) / a0)
+    b1 = f(float(f(-2 * A * ((A - 1) + (A + 1) * cw))) / a0)
+    b2 = f(float(f(A * ((A + 1) + (A - 1) * cw - beta * sw))) / a0)
+    a1 = f(float(f(2 * ((A - 1) - (A + 1) * cw))) / -a0)
+    a2 = f(float(f((A + 1) - (A - 1) * cw - beta * sw)) / -a0)
     return [b0, b1, b2, a1, a2]
 
 
 class Proc:
     def __init__(self):
-        self.c = [0.0] * 5  # b0 b1 b2 a1 a2, zero-initialised
-        self.h = [0.0] * 4  # ha1 ha2 hb1 hb2
+        z = np.float32(0.0)
+        self.c = [z] * 5  # b0 b1 b2 a1 a2, zero-initialised
+        self.h = [z] * 4  # ha1 ha2 hb1 hb2
 
     def run(self, xs, target, clear):
-        n = len(xs)
+        n = np.float32(len(xs))
         if clear:
-            self.h = [0.0] * 4
+            self.h = [np.float32(0.0)] * 4
         inc = [(t - c) / n for t, c in zip(target, self.c)]  # update_coeffs(len): ramp from the current coefficients
         out = []
         for x in xs:
+            x = np.float32(x)
             b0, b1, b2, a1, a2 = self.c
             ha1, ha2, hb1, hb2 = self.h
             y = x * b0 + hb1 * b1 + hb2 * b2 + ha1 * a1 + ha2 * a2
@@ -61,13 +67,14 @@ class Twin3D:
 
     def mix_channel(self, mixv, gain, cutoff, c, src):
         F = len(src)
+        f = np.float32
         vs, vf = self.get_prev(c), mixv[c]
-        out = np.zeros((F, 2))
-        scaled = np.zeros((F, 2))
+        out = np.zeros((F, 2), np.float32)
+        scaled = np.zeros((F, 2), np.float32)
         for i in range(F):
-            t = i / F
+            t = f(i) / f(F)
             for ear in range(2):
-                scaled[i, ear] = (vf[ear] * t + (1 - t) * vs[ear]) * src[i, ear]
+                scaled[i, ear] = (f(vf[ear]) * t + (f(1) - t) * f(vs[ear])) * f(src[i, ear])
         if gain >= 0.001:
             target = highshelf64(48000.0, cutoff, gain)
             clear = vs[0] == 0 and vs[1] == 0
@@ -85,7 +92,7 @@ class Twin3D:
             clear = pv[0] == 0 and pv[1] == 0
             out = np.stack([self.procs[ear].run(src[:, ear], target, clear) for ear in range(2)], axis=1)
         else:
-            out = src.astype(np.float64).copy()
+            out = src.astype(np.float32).copy()
         best, idx = 0.0, 0
         for i in range(4):  # strict '>', first wins, all-zero -> pair 0
             for ear in range(2):
@@ -110,7 +117,7 @@ def schedule(rng, blocks):
 
 
 @pytest.mark.parametrize("mode", ["mix_channel", "process_frames"])
-def test_float64_twin_agrees_with_c_oracle(ob, mode):
+def test_float32_twin_agrees_with_c_oracle(ob, mode):
     rng = np.random.default_rng(17)
     F, blocks = 512, 9
     sched = schedule(rng, blocks)
@@ -129,9 +136,9 @@ def test_float64_twin_agrees_with_c_oracle(ob, mode):
         got, _, _ = ora.block(p, src[None])
         if mode == "mix_channel":
             for c in range(2):
-                want = twin.mix_channel(mv32, g32, c32, c, src.astype(np.float64))
-                scale = max(np.sqrt(np.mean(want**2)), 1e-9)
-                assert np.sqrt(np.mean((got[c] - want) ** 2)) / scale < 1e-4, (b, c)
+                want = twin.mix_channel(mv32, g32, c32, c, src)
+                scale = max(np.sqrt(np.mean(want.astype(np.float64) ** 2)), 1e-9)
+                assert np.sqrt(np.mean((got[c] - want.astype(np.float64)) ** 2)) / scale < 2e-6, (b, c)
         else:
-            want = twin.process_frames(mv32, g32, c32, src.astype(np.float64))
-            assert rel_rms(got[0], want) < 1e-4, b
+            want = twin.process_frames(mv32, g32, c32, src)
+            assert rel_rms(got[0], want) < 2e-6, b
