@@ -21,6 +21,13 @@
 // at N = 256 it is latency-bound on the F-step recurrence (8 waves on a 256-CU part) -- DESIGN.md.
 #include "gas_internal.h"
 
+// No FMA contraction in this file.  The recurrence is f32 with poles that approach the unit circle at low cutoffs /
+// small shelf gains (|p| up to 0.999x); there a fused multiply-add in place of the reference's separately rounded
+// multiply and add moves the output by up to 1e-3 relative (measured: 9e-4 at 50 Hz), far outside the 1e-5 parity bar,
+// while with identical rounding the kernel tracks the CPU restatement to ~1e-7 at every setting.  Costs ~4 more VALU
+// instructions per step.
+#pragma clang fp contract(off)
+
 namespace {
 
 constexpr int SRC_PER_WG = 32;

@@ -164,3 +164,20 @@ def test_hrtf_direction_crossfade(gas, ob, mode, frames):
     flags = K.FLAG_HRTF_CROSSFADE | (K.FLAG_PEAKS_DRAINING_ONLY if mode == "frequency_domain" else 0)
     chain = (K.FX_EARLY_REFLECTIONS, K.FX_HRTF) if mode == "er_chain" else (K.FX_HRTF,)
     run_pair(gas, ob, K.KIND_EFFECT, chain, 150, frames, 8, hrir=hrir, flags=flags, draining_every=9, ring=4096 if mode == "er_chain" else 0)
+
+
+@pytest.mark.parametrize("cutoff", [50.0, 500.0, 20500.0])
+@pytest.mark.parametrize("gain", [0.0011, 0.05, 1.0])
+def test_biquad_extreme_filter_settings(gas, ob, cutoff, gain):
+    """Low cutoffs / small shelf gains put the poles almost on the unit circle, where the f32 recurrence amplifies any
+    rounding difference (an FMA in place of mul + add: up to 9e-4).  The kernel is compiled without FMA contraction so
+    it rounds like the reference arithmetic and stays inside the 1e-5 bar at every legal setting."""
+
+    def hook(b, p):
+        p["linear_attenuation"] = gain
+        p["fx_shelf_gain"] = gain
+        p["attenuation_filter_cutoff_hz"] = cutoff
+        p["fx_shelf_cutoff_hz"] = cutoff
+
+    run_pair(gas, ob, gas.capi.KIND_3D_MIX, (), 48, 512, 10, params_hook=hook)
+    run_pair(gas, ob, gas.capi.KIND_EFFECT, (gas.capi.FX_HIGHSHELF,), 40, 512, 6, params_hook=hook)
