@@ -407,6 +407,7 @@ class BatchedSpatializerHost:
         L.gas_host_destroy.restype = None
         L.gas_host_start_playback_array.argtypes = [vp, vp, C.c_int64, C.POINTER(u32)]
         L.gas_host_stop_playback.argtypes = [vp, u32]
+        L.gas_host_start_playback_device_stream.argtypes = [vp, u32, C.c_uint64, C.POINTER(u32)]
         L.gas_host_set_spatializer_parameters.argtypes = [vp, u32, vp]
         L.gas_host_set_playback_disable_threshold_db.argtypes = [vp, C.c_float]
         L.gas_host_set_playback_disable_threshold_db.restype = None
@@ -429,6 +430,11 @@ class BatchedSpatializerHost:
         self._streams.append(s)  # the host reads it on every callback: keep it alive
         pid = C.c_uint32()
         self.ctx._check(self.lib.gas_host_start_playback_array(self.h, _np_ptr(s), s.shape[0], C.byref(pid)), "gas_host_start_playback_array")
+        return pid.value
+
+    def start_playback_device_stream(self, stream_id, start_frame=0):
+        pid = C.c_uint32()
+        self.ctx._check(self.lib.gas_host_start_playback_device_stream(self.h, int(stream_id), int(start_frame), C.byref(pid)), "gas_host_start_playback_device_stream")
         return pid.value
 
     def stop_playback(self, pid):

@@ -1058,7 +1058,7 @@ int gas_process_block_streams(gas_ctx *c, const uint32_t *slots, uint32_t n, uin
 	}
 	// Steady state: same slot list as the previous stream callback, launch groups still cached, no parameter or
 	// binding change since -> skip validation and work on the compact row mirror.
-	bool same_list = c->stream_rows.size() == n && c->cached_n == n && c->stream_groups_gen == c->groups_gen && !c->stream_params_touched && c->stream_slots_host.size() == n && (n == 0 || std::memcmp(c->stream_slots_host.data(), slots, (size_t)n * sizeof(uint32_t)) == 0);
+	bool same_list = c->pending_free.empty() /* a deferred free re-sorts the groups */ && c->stream_rows.size() == n && c->cached_n == n && c->stream_groups_gen == c->groups_gen && !c->stream_params_touched && c->stream_slots_host.size() == n && (n == 0 || std::memcmp(c->stream_slots_host.data(), slots, (size_t)n * sizeof(uint32_t)) == 0);
 	if (!same_list) {
 		stream_rows_sync_back(c);
 		for (uint32_t i = 0; i < n; i++) {

@@ -23,6 +23,7 @@ struct PlaybackNode {
 	bool has_params = false;
 	gas_params params{};
 	gas_audio_frame lookahead[LOOKAHEAD]{};
+	bool device_stream = false; // sampled on the GPU (gas_host_start_playback_device_stream)
 	// array-backed stream (gas_host_start_playback_array)
 	const gas_audio_frame *array = nullptr;
 	int64_t array_frames = 0, array_pos = 0;
@@ -64,6 +65,8 @@ struct gas_host {
 	std::vector<float> peaks;
 	std::vector<gas_audio_frame> mix_buffer; // [ctx_channels][n]
 	bool mix_valid = false;
+	int mode = 0; // 0 undecided, 1 callback/array playbacks, 2 device-stream playbacks
+	std::vector<uint8_t> has_frames_out;
 
 	PlaybackNode *find(uint32_t id) {
 		for (auto &n : list) {
@@ -120,6 +123,35 @@ struct gas_host {
 		rows.clear();
 		slots.clear();
 		row_node.clear();
+		if (mode == 2) {
+			// device-resident streams: the library samples the windows itself and reports has_frames per row
+			for (auto &up : list) {
+				PlaybackNode *pb = up.get();
+				if (pb->active && pb->has_params) {
+					slots.push_back(pb->slot);
+					row_node.push_back(pb);
+				}
+			}
+			const uint32_t count = (uint32_t)slots.size();
+			peaks.assign((size_t)count * 2 + 2, 0.0f);
+			has_frames_out.assign((size_t)count + 1, 0);
+			const int rc = gas_process_block_streams(ctx, slots.data(), count, (uint32_t)n, mix_buffer.data(), peaks.data(), has_frames_out.data(), GAS_MEM_HOST);
+			if (rc != GAS_OK) {
+				return rc;
+			}
+			const float threshold = db_to_linear(disable_threshold_db);
+			for (uint32_t r = 0; r < count; r++) {
+				PlaybackNode *pb = row_node[r];
+				pb->has_frames = has_frames_out[r] != 0; // audio_spatializer.cpp:398
+				if (!pb->has_frames) { // :464-469
+					const float l = peaks[2 * r], rr = peaks[2 * r + 1];
+					if ((rr > l ? rr : l) <= threshold) {
+						pb->active = false;
+					}
+				}
+			}
+			return GAS_OK;
+		}
 		for (auto &up : list) {
 			PlaybackNode *pb = up.get();
 			if (!pb->active) { // :355-357
@@ -224,6 +256,10 @@ int gas_host_start_playback(gas_host *h, gas_host_stream_mix_fn mix, void *user,
 	if (!h || !mix || !out_id) {
 		return GAS_ERR_INVALID_ARGUMENT;
 	}
+	if (h->mode == 2) {
+		return GAS_ERR_KIND_MISMATCH;
+	}
+	h->mode = 1;
 	std::unique_ptr<PlaybackNode> n(new (std::nothrow) PlaybackNode());
 	if (!n) {
 		return GAS_ERR_OUT_OF_MEMORY;
@@ -257,6 +293,39 @@ int gas_host_start_playback_array(gas_host *h, const gas_audio_frame *stream, in
 	n->user = n;
 	n->array = stream;
 	n->array_frames = stream_frames;
+	return GAS_OK;
+}
+
+int gas_host_start_playback_device_stream(gas_host *h, uint32_t stream, uint64_t start_frame, uint32_t *out_id) {
+	if (!h || !out_id) {
+		return GAS_ERR_INVALID_ARGUMENT;
+	}
+	if (h->mode == 1) {
+		return GAS_ERR_KIND_MISMATCH;
+	}
+	std::unique_ptr<PlaybackNode> n(new (std::nothrow) PlaybackNode());
+	if (!n) {
+		return GAS_ERR_OUT_OF_MEMORY;
+	}
+	int rc = gas_source_alloc(h->ctx, h->kind, h->effects.data(), (uint32_t)h->effects.size(), &n->slot);
+	if (rc != GAS_OK) {
+		return rc;
+	}
+	rc = gas_source_bind_stream(h->ctx, n->slot, stream, start_frame);
+	if (rc != GAS_OK) {
+		gas_source_free(h->ctx, n->slot);
+		return rc;
+	}
+	h->mode = 2;
+	n->id = h->next_id++;
+	n->device_stream = true;
+	*out_id = n->id;
+	if (h->list.empty()) {
+		for (bool &m : h->channel_mixed) {
+			m = true;
+		}
+	}
+	h->list.insert(h->list.begin(), std::move(n));
 	return GAS_OK;
 }
 

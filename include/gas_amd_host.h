@@ -31,6 +31,10 @@ void gas_host_destroy(gas_host *host);
 int gas_host_start_playback(gas_host *host, gas_host_stream_mix_fn mix, void *user, uint32_t *out_id);
 /* Convenience for tests/tools: a playback over a caller-owned array of frames (zero-filled past its end). */
 int gas_host_start_playback_array(gas_host *host, const gas_audio_frame *stream, int64_t stream_frames, uint32_t *out_id);
+/* A playback over a device-resident stream (gas_stream_create): nothing crosses PCIe per callback, the source window
+ * and fade-out are produced on the GPU (gas_process_block_streams).  A host serves either callback/array playbacks
+ * or device-stream playbacks, not a mixture (GAS_ERR_KIND_MISMATCH). */
+int gas_host_start_playback_device_stream(gas_host *host, uint32_t stream, uint64_t start_frame, uint32_t *out_id);
 /* stop_playback_stream (audio_spatializer.cpp:98-113): active = false; the audio thread reaps it. */
 int gas_host_stop_playback(gas_host *host, uint32_t id);
 /* set_spatializer_parameters (audio_spatializer.cpp:558-564), per playback. */
