@@ -23,12 +23,13 @@ enum gas_group_type {
 	G_FX_HRTF_PK, // per-source inverse FFTs: exact peaks (draining playbacks / peaks-for-all contexts); launched with G_FX_HRTF
 	G_FX_ER_HRTF,
 	G_FX_ER_HRTF_PK, // launched with G_FX_ER_HRTF
+	G_FX_GENERIC, // any other chain of the implemented effects: staged through ping-pong row buffers (audio_spatializer_effect.cpp:52-76)
 	G_COUNT
 };
 
 const char *const k_group_kernel[G_COUNT] = {
 	"k_biquad_mix<MIX_CHANNEL>", "k_biquad_mix<PROCESS_FRAMES>", "k_biquad_mix<COPY>", "k_biquad_mix<FX_HIGHSHELF>",
-	"k_er_only", "k_hrtf_ols", "k_hrtf_ols", "k_hrtf_ols<ER>", "k_hrtf_ols<ER>"
+	"k_er_only", "k_hrtf_ols", "k_hrtf_ols", "k_hrtf_ols<ER>", "k_hrtf_ols<ER>", "staged effect chain"
 };
 
 struct SlotInfo {
@@ -38,6 +39,7 @@ struct SlotInfo {
 	uint8_t has_params = 0;
 	uint8_t pending_free = 0;
 	uint8_t dirty_state = 0; // state must be zeroed before reuse
+	uint16_t chain_sig = 0; // G_FX_GENERIC: effect kinds, 4 bits each, first effect in the low nibble
 	uint8_t draining = 0; // stream ended: the host's silence gate needs this source's peak (audio_spatializer.cpp:464)
 };
 
@@ -45,6 +47,12 @@ struct Group {
 	uint32_t offset = 0, count = 0;
 	bool contiguous = false; // the group's slots are slot_base, slot_base + 1, ... in order
 	uint32_t slot_base = 0;
+};
+
+// One run of G_FX_GENERIC entries that share a chain.
+struct ChainRange {
+	uint16_t sig = 0;
+	uint32_t offset = 0, count = 0; // relative to the group's offset
 };
 
 constexpr uint32_t PROFILE_EVENTS = 4096;
@@ -83,6 +91,9 @@ struct gas_ctx {
 	uint64_t stream_groups_gen = UINT64_MAX; // groups_gen the stream path's cached list corresponds to
 	bool cached_identity_rows = true;
 	Group groups[G_COUNT];
+	std::vector<ChainRange> chain_ranges; // sub-runs of groups[G_FX_GENERIC], cached with the groups
+	gas_audio_frame *d_chain[2] = { nullptr, nullptr }; // ping-pong rows of the staged chains
+	size_t d_chain_frames = 0;
 
 	gas_audio_frame *d_src = nullptr; // staging for GAS_MEM_HOST, lazily sized
 	size_t d_src_frames = 0;
@@ -176,11 +187,41 @@ int group_of(int kind, const int32_t *fx, uint32_t n_fx) {
 	if (n_fx == 2 && fx[0] == GAS_FX_EARLY_REFLECTIONS && fx[1] == GAS_FX_HRTF) {
 		return G_FX_ER_HRTF;
 	}
-	return -2; // a chain without a fused kernel yet
+	// any other order / combination of the implemented effects runs staged; the per-slot state allows one early-
+	// reflection ring and one HRTF history per playback
+	int n_er = 0, n_hrtf = 0;
+	for (uint32_t j = 0; j < n_fx; j++) {
+		if (fx[j] != GAS_FX_HIGHSHELF && fx[j] != GAS_FX_EARLY_REFLECTIONS && fx[j] != GAS_FX_HRTF) {
+			return -1;
+		}
+		n_er += fx[j] == GAS_FX_EARLY_REFLECTIONS;
+		n_hrtf += fx[j] == GAS_FX_HRTF;
+	}
+	if (n_er > 1 || n_hrtf > 1) {
+		return -2;
+	}
+	return G_FX_GENERIC;
+}
+
+uint16_t chain_signature(const int32_t *fx, uint32_t n_fx) {
+	uint16_t sig = 0;
+	for (uint32_t j = 0; j < n_fx; j++) {
+		sig |= (uint16_t)(fx[j] & 0xf) << (4 * j);
+	}
+	return sig;
+}
+
+bool chain_has(uint16_t sig, int kind) {
+	for (int j = 0; j < 4; j++) {
+		if (((sig >> (4 * j)) & 0xf) == kind) {
+			return true;
+		}
+	}
+	return false;
 }
 
 // Partial mixes each launch group writes (must mirror the launchers' grids).
-void plan_partials(const Group *groups, uint32_t *pcount) {
+void plan_partials(const Group *groups, const std::vector<ChainRange> &ranges, uint32_t *pcount) {
 	for (int gt = 0; gt < G_COUNT; gt++) {
 		pcount[gt] = 0;
 	}
@@ -193,6 +234,11 @@ void plan_partials(const Group *groups, uint32_t *pcount) {
 		gas_hrtf_plan(groups[gt].count, groups[gt + 1].count, &p);
 		pcount[gt] = p.wgs_fd;
 		pcount[gt + 1] = p.wgs_pk;
+	}
+	if (groups[G_FX_GENERIC].count) {
+		for (const ChainRange &r : ranges) {
+			pcount[G_FX_GENERIC] += gas_hrtf_partials(r.count, nullptr);
+		}
 	}
 }
 
@@ -249,10 +295,10 @@ int ensure_partials(gas_ctx *c, uint32_t rows) {
 }
 
 // Device work of one callback over already-grouped entries.
-int run_groups(gas_ctx *c, const gas_audio_frame *d_src, const uint32_t *d_slots, const uint32_t *d_rows, const Group *groups, uint32_t n_total, gas_audio_frame *d_out, float *d_peaks, uint32_t channel_begin, uint32_t channel_count, int force_mode) {
+int run_groups(gas_ctx *c, const gas_audio_frame *d_src, const uint32_t *d_slots, const uint32_t *d_rows, const Group *groups, const std::vector<ChainRange> &ranges, uint32_t n_total, gas_audio_frame *d_out, float *d_peaks, uint32_t channel_begin, uint32_t channel_count, int force_mode) {
 	const uint32_t F = c->cfg.frames;
 	uint32_t pcount[G_COUNT];
-	plan_partials(groups, pcount);
+	plan_partials(groups, ranges, pcount);
 	uint32_t p_total = 0, p_mix = 0;
 	for (int gt = 0; gt < G_COUNT; gt++) {
 		p_total += pcount[gt];
@@ -348,6 +394,57 @@ int run_groups(gas_ctx *c, const gas_audio_frame *d_src, const uint32_t *d_slots
 					g_pk.slot_base = groups[fd_gt + 1].slot_base;
 				}
 				e = gas_launch_hrtf_ols(c->stream, fd_gt == G_FX_ER_HRTF, (c->cfg.flags & GAS_FLAG_HRTF_CROSSFADE) != 0, g_fd, g_pk, c->st, c->tab, c->d_tw, F, c->hist_len, c->cfg.er_ring_frames, c->d_partials, p_off, fd_gt == G_FX_HRTF && c->fused_streams ? c->d_cursors : nullptr, c->d_fade_env, fd_gt == G_FX_HRTF ? c->fresh_for_launch : nullptr);
+			} break;
+			case G_FX_GENERIC: {
+				// audio_spatializer_effect.cpp:52-76 on the device: effect j reads the previous stage's rows and writes
+				// the other ping-pong buffer; the last stage's rows are mixed by k_rows_accumulate
+				size_t need = 0;
+				for (const ChainRange &r : ranges) {
+					need = need > (size_t)r.count * F ? need : (size_t)r.count * F;
+				}
+				if (need > c->d_chain_frames) {
+					GAS_HIP(c, hipStreamSynchronize(c->stream));
+					(void)hipFree(c->d_chain[0]);
+					(void)hipFree(c->d_chain[1]);
+					c->d_chain[0] = c->d_chain[1] = nullptr;
+					c->d_chain_frames = 0;
+					GAS_HIP(c, hipMalloc(&c->d_chain[0], need * sizeof(gas_audio_frame)));
+					GAS_HIP(c, hipMalloc(&c->d_chain[1], need * sizeof(gas_audio_frame)));
+					c->d_chain_frames = need;
+				}
+				uint32_t pp = p_off;
+				for (const ChainRange &r : ranges) {
+					const uint32_t off = gr.offset + r.offset;
+					gas_group_args in = ga;
+					in.n = r.count;
+					in.slots = d_slots + off;
+					in.rows = d_rows ? d_rows + off : nullptr;
+					in.src = d_rows ? d_src : d_src + (size_t)off * F; // identity rows: the run's first row is entry `off`
+					in.peaks = d_rows ? d_peaks : d_peaks + (size_t)off * 2;
+					const uint32_t *peak_rows = in.rows;
+					for (int j = 0; j < 4 && e == hipSuccess; j++) {
+						const int kind = (r.sig >> (4 * j)) & 0xf;
+						if (!kind) {
+							break;
+						}
+						gas_audio_frame *outb = c->d_chain[j & 1];
+						if (kind == GAS_FX_HIGHSHELF) {
+							e = gas_launch_biquad_mix(c->stream, GAS_MODE_FX_HIGHSHELF, in, c->st, F, (uint32_t)j, 1, c->cfg.mix_rate, c->d_partials, 0, c->partial_rows, reinterpret_cast<float *>(outb));
+						} else if (kind == GAS_FX_EARLY_REFLECTIONS) {
+							e = gas_launch_er_only(c->stream, in, c->st, F, c->cfg.er_ring_frames, c->d_partials, 0, c->partial_rows, outb);
+						} else {
+							e = gas_launch_hrtf_rows(c->stream, (c->cfg.flags & GAS_FLAG_HRTF_CROSSFADE) != 0, in, c->st, c->tab, c->d_tw, F, outb);
+						}
+						in.src = outb; // dense rows from here on
+						in.rows = nullptr;
+					}
+					if (e == hipSuccess) {
+						gas_group_args fin = in;
+						fin.rows = peak_rows; // peaks go to the callback's row of each source
+						e = gas_launch_rows_accumulate(c->stream, fin, F, c->d_partials, pp);
+					}
+					pp += gas_hrtf_partials(r.count, nullptr);
+				}
 			} break;
 			case G_FX_ER:
 				e = gas_launch_er_only(c->stream, ga, c->st, F, c->cfg.er_ring_frames, c->d_partials, p_off, c->partial_rows);
@@ -472,6 +569,32 @@ int build_groups(gas_ctx *c, const uint32_t *slots, uint32_t n) {
 		hs[p] = slots[i];
 		hr[p] = i;
 	}
+	c->chain_ranges.clear();
+	if (c->groups[G_FX_GENERIC].count) { // runs of equal chains inside the staged group (stable: input order kept within a run)
+		const Group &gg = c->groups[G_FX_GENERIC];
+		std::vector<uint32_t> order(gg.count);
+		for (uint32_t k = 0; k < gg.count; k++) {
+			order[k] = k;
+		}
+		std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return c->slots[hs[gg.offset + a]].chain_sig < c->slots[hs[gg.offset + b]].chain_sig; });
+		std::vector<uint32_t> ts(gg.count), tr(gg.count);
+		for (uint32_t k = 0; k < gg.count; k++) {
+			ts[k] = hs[gg.offset + order[k]];
+			tr[k] = hr[gg.offset + order[k]];
+		}
+		for (uint32_t k = 0; k < gg.count; k++) {
+			hs[gg.offset + k] = ts[k];
+			hr[gg.offset + k] = tr[k];
+			const uint16_t sig = c->slots[ts[k]].chain_sig;
+			if (c->chain_ranges.empty() || c->chain_ranges.back().sig != sig) {
+				ChainRange r;
+				r.sig = sig;
+				r.offset = k;
+				c->chain_ranges.push_back(r);
+			}
+			c->chain_ranges.back().count++;
+		}
+	}
 	for (int gt = 0; gt < G_COUNT; gt++) {
 		Group &gr = c->groups[gt];
 		gr.contiguous = gr.count > 0;
@@ -480,7 +603,7 @@ int build_groups(gas_ctx *c, const uint32_t *slots, uint32_t n) {
 			gr.contiguous = hs[gr.offset + k] == gr.slot_base + k;
 		}
 	}
-	c->cached_identity_rows = nonempty <= 1;
+	c->cached_identity_rows = nonempty <= 1 && c->chain_ranges.size() <= 1;
 	if (n > 0) {
 		GAS_HIP(c, hipMemcpyAsync(c->d_slots, hs, (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
 		if (!c->cached_identity_rows) {
@@ -495,7 +618,11 @@ int build_groups(gas_ctx *c, const uint32_t *slots, uint32_t n) {
 }
 
 int needs_hrtf(const gas_ctx *c) {
-	return (c->groups[G_FX_HRTF].count > 0 || c->groups[G_FX_ER_HRTF].count > 0 || c->groups[G_FX_HRTF_PK].count > 0 || c->groups[G_FX_ER_HRTF_PK].count > 0) && c->tab.spec == nullptr;
+	bool any = c->groups[G_FX_HRTF].count > 0 || c->groups[G_FX_ER_HRTF].count > 0 || c->groups[G_FX_HRTF_PK].count > 0 || c->groups[G_FX_ER_HRTF_PK].count > 0;
+	for (const ChainRange &r : c->chain_ranges) {
+		any = any || chain_has(r.sig, GAS_FX_HRTF);
+	}
+	return any && c->tab.spec == nullptr;
 }
 
 } // namespace
@@ -569,6 +696,8 @@ void gas_ctx_destroy(gas_ctx *c) {
 	(void)hipFree(c->d_rows);
 	(void)hipFree(c->d_slots_rows);
 	(void)hipFree(c->d_src);
+	(void)hipFree(c->d_chain[0]);
+	(void)hipFree(c->d_chain[1]);
 	(void)hipFree(c->d_out);
 	(void)hipFree(c->d_peaks);
 	(void)hipFree(c->d_partials);
@@ -739,7 +868,8 @@ int gas_source_alloc(gas_ctx *c, int kind, const int32_t *effects, uint32_t n_ef
 	if (g == -2) {
 		return GAS_ERR_UNSUPPORTED_CHAIN;
 	}
-	if ((g == G_FX_ER || g == G_FX_ER_HRTF) && c->cfg.er_ring_frames == 0) {
+	const uint16_t sig = g == G_FX_GENERIC ? chain_signature(effects, n_effects) : 0;
+	if ((g == G_FX_ER || g == G_FX_ER_HRTF || (g == G_FX_GENERIC && chain_has(sig, GAS_FX_EARLY_REFLECTIONS))) && c->cfg.er_ring_frames == 0) {
 		return GAS_ERR_UNSUPPORTED_CHAIN;
 	}
 	if (c->free_list.empty()) {
@@ -755,6 +885,7 @@ int gas_source_alloc(gas_ctx *c, int kind, const int32_t *effects, uint32_t n_ef
 	si.used = 1;
 	si.kind = (uint8_t)kind;
 	si.group = (uint8_t)g;
+	si.chain_sig = sig;
 	c->slots[s] = si;
 	*out_slot = s;
 	return GAS_OK;
@@ -1122,6 +1253,8 @@ int gas_process_block_streams(gas_ctx *c, const uint32_t *slots, uint32_t n, uin
 			if (c->d_src) {
 				(void)hipStreamSynchronize(c->stream);
 				(void)hipFree(c->d_src);
+	(void)hipFree(c->d_chain[0]);
+	(void)hipFree(c->d_chain[1]);
 				c->d_src = nullptr;
 				c->d_src_frames = 0;
 			}
@@ -1247,6 +1380,8 @@ int gas_process_block(gas_ctx *c, const gas_audio_frame *src, const uint32_t *sl
 		if (need > c->d_src_frames) {
 			if (c->d_src) {
 				(void)hipFree(c->d_src);
+	(void)hipFree(c->d_chain[0]);
+	(void)hipFree(c->d_chain[1]);
 				c->d_src = nullptr;
 				c->d_src_frames = 0;
 			}
@@ -1281,7 +1416,7 @@ int gas_process_block(gas_ctx *c, const gas_audio_frame *src, const uint32_t *sl
 			}
 		}
 	}
-	rc = run_groups(c, d_src, c->d_slots, c->cached_identity_rows ? nullptr : c->d_rows, c->groups, n, d_out, d_peaks, 0, C, -1);
+	rc = run_groups(c, d_src, c->d_slots, c->cached_identity_rows ? nullptr : c->d_rows, c->groups, c->chain_ranges, n, d_out, d_peaks, 0, C, -1);
 	c->fresh_for_launch = nullptr;
 	if (rc != GAS_OK) {
 		return fail(rc);
@@ -1354,6 +1489,8 @@ static int process_one(gas_ctx *c, uint32_t slot, int channel, bool mix_channel,
 	if (c->d_src_frames < F) {
 		if (c->d_src) {
 			(void)hipFree(c->d_src);
+	(void)hipFree(c->d_chain[0]);
+	(void)hipFree(c->d_chain[1]);
 			c->d_src = nullptr;
 			c->d_src_frames = 0;
 		}
@@ -1362,7 +1499,17 @@ static int process_one(gas_ctx *c, uint32_t slot, int channel, bool mix_channel,
 	}
 	GAS_HIP(c, hipMemcpyAsync(c->d_one_slot, &slot, sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
 	GAS_HIP(c, hipMemcpyAsync(c->d_src, src, (size_t)F * sizeof(gas_audio_frame), hipMemcpyHostToDevice, c->stream));
-	rc = run_groups(c, c->d_src, c->d_one_slot, nullptr, groups, 1, c->d_out, c->d_peaks, mix_channel ? (uint32_t)channel : 0, 1, force_mode);
+	std::vector<ChainRange> one_range;
+	if (gt == G_FX_GENERIC) {
+		ChainRange r;
+		r.sig = si.chain_sig;
+		r.count = 1;
+		one_range.push_back(r);
+		if (chain_has(r.sig, GAS_FX_HRTF) && c->tab.spec == nullptr) {
+			return GAS_ERR_NO_HRTF;
+		}
+	}
+	rc = run_groups(c, c->d_src, c->d_one_slot, nullptr, groups, one_range, 1, c->d_out, c->d_peaks, mix_channel ? (uint32_t)channel : 0, 1, force_mode);
 	if (rc != GAS_OK) {
 		return rc;
 	}

@@ -90,7 +90,7 @@ struct LaneState {
 // The tile loop, specialised on the two wave-uniform conditions so neither the IEEE division of the
 // non-power-of-two lerp nor the bypass-branch selects are evaluated per step.
 template <int MODE, bool F_POW2, bool ALL_FILT>
-__device__ __forceinline__ void run_tiles(LaneState &L, float (&tile)[2][SRC_PER_WG * ROW], const float *const (&ld_base)[LOADS], uint32_t F, float *__restrict__ my_partial, int lane, int sl, int ear) {
+__device__ __forceinline__ void run_tiles(LaneState &L, float (&tile)[2][SRC_PER_WG * ROW], const float *const (&ld_base)[LOADS], uint32_t F, float *__restrict__ my_partial, int lane, int sl, int ear, const bool rows_mode, float *const (&st_base)[LOADS]) {
 	Coeffs co = L.co, inc = L.inc;
 	float ha1 = L.ha1, ha2 = L.ha2, hb1 = L.hb1, hb2 = L.hb2;
 	const float vs = L.vs, vf = L.vf;
@@ -181,6 +181,18 @@ __device__ __forceinline__ void run_tiles(LaneState &L, float (&tile)[2][SRC_PER
 		}
 		__syncthreads();
 
+		if (rows_mode) { // wave-uniform
+			// rows-out (a stage of a general effect chain): hand the processed tile back as per-source rows, with the
+			// staging loads' own coalesced pattern; no sum here -- k_rows_accumulate mixes the chain's last stage
+#pragma unroll
+			for (int q = 0; q < LOADS; q++) {
+				if (st_base[q]) {
+					const int idx = q * 64 + lane;
+					const float *t4 = tb + (idx / PARTS) * ROW + (idx % PARTS) * 4;
+					*reinterpret_cast<float4 *>(st_base[q] + (size_t)tl * KF * 2) = make_float4(t4[0], t4[1], t4[2], t4[3]);
+				}
+			}
+		} else {
 		// role switch: lane (h, j) sums column j = frame*2+ear over its group's sources, in order; the groups
 		// (two at KF = 16) are then added in order too
 		{
@@ -200,6 +212,7 @@ __device__ __forceinline__ void run_tiles(LaneState &L, float (&tile)[2][SRC_PER
 				my_partial[(size_t)tl * COLS + j] = s;
 			}
 		}
+		}
 		// the next iteration writes the other buffer; this one is rewritten two tiles later,
 		// after the __syncthreads() that follows that write.
 	}
@@ -213,7 +226,7 @@ __device__ __forceinline__ void run_tiles(LaneState &L, float (&tile)[2][SRC_PER
 }
 
 template <int MODE>
-__global__ __launch_bounds__(64) void k_biquad_mix(gas_group_args g, gas_dev_state st, uint32_t F, uint32_t c0, float mix_rate, float *__restrict__ partials, uint32_t p_offset, uint32_t p_stride) {
+__global__ __launch_bounds__(64) void k_biquad_mix(gas_group_args g, gas_dev_state st, uint32_t F, uint32_t c0, float mix_rate, float *__restrict__ partials, uint32_t p_offset, uint32_t p_stride, float *__restrict__ rows_out) {
 	__shared__ float tile[2][SRC_PER_WG * ROW];
 
 	const int lane = threadIdx.x;
@@ -238,6 +251,15 @@ __global__ __launch_bounds__(64) void k_biquad_mix(gas_group_args g, gas_dev_sta
 		uint32_t lrow = g.rows ? g.rows[le] : le;
 		ld_base[q] = reinterpret_cast<const float *>(g.src) + (size_t)lrow * F * 2 + (idx % PARTS) * 4;
 	}
+	// rows-out: dense rows by group entry; entries past the end are not written
+	float *st_base[LOADS];
+#pragma unroll
+	for (int q = 0; q < LOADS; q++) {
+		const int idx = q * 64 + lane;
+		const uint32_t le = blockIdx.x * SRC_PER_WG + (idx / PARTS);
+		st_base[q] = (rows_out && le < g.n) ? rows_out + (size_t)le * F * 2 + (idx % PARTS) * 4 : nullptr;
+	}
+
 
 	// ---- per-lane DSP state (SpatializerPlaybackData3D, audio_spatializer_3d.h:85-99) ----
 	const size_t stream = ((size_t)slot * 4 + c) * 2 + ear;
@@ -308,15 +330,15 @@ __global__ __launch_bounds__(64) void k_biquad_mix(gas_group_args g, gas_dev_sta
 	LaneState L{ co, inc, ha1, ha2, hb1, hb2, vs, vf, 0.0f, filt, valid };
 	if (f_pow2) {
 		if (all_filt) {
-			run_tiles<MODE, true, true>(L, tile, ld_base, F, my_partial, lane, sl, ear);
+			run_tiles<MODE, true, true>(L, tile, ld_base, F, my_partial, lane, sl, ear, rows_out != nullptr, st_base);
 		} else {
-			run_tiles<MODE, true, false>(L, tile, ld_base, F, my_partial, lane, sl, ear);
+			run_tiles<MODE, true, false>(L, tile, ld_base, F, my_partial, lane, sl, ear, rows_out != nullptr, st_base);
 		}
 	} else {
 		if (all_filt) {
-			run_tiles<MODE, false, true>(L, tile, ld_base, F, my_partial, lane, sl, ear);
+			run_tiles<MODE, false, true>(L, tile, ld_base, F, my_partial, lane, sl, ear, rows_out != nullptr, st_base);
 		} else {
-			run_tiles<MODE, false, false>(L, tile, ld_base, F, my_partial, lane, sl, ear);
+			run_tiles<MODE, false, false>(L, tile, ld_base, F, my_partial, lane, sl, ear, rows_out != nullptr, st_base);
 		}
 	}
 	co = L.co;
@@ -344,7 +366,9 @@ __global__ __launch_bounds__(64) void k_biquad_mix(gas_group_args g, gas_dev_sta
 			bq[BQ_PREV * bs + stream] = vf; // set_prev_mix_volume (:551, :608)
 		}
 		// per-source peak over all its channel pairs (:419-444): max is order-independent
-		atomicMax(reinterpret_cast<unsigned int *>(g.peaks) + (size_t)row * 2 + ear, __float_as_uint(peak));
+		if (!rows_out) {
+			atomicMax(reinterpret_cast<unsigned int *>(g.peaks) + (size_t)row * 2 + ear, __float_as_uint(peak));
+		}
 	}
 }
 
@@ -354,7 +378,7 @@ uint32_t gas_biquad_partials(uint32_t n) {
 	return (n + SRC_PER_WG - 1) / SRC_PER_WG;
 }
 
-hipError_t gas_launch_biquad_mix(hipStream_t stream, int mode, const gas_group_args &g, const gas_dev_state &st, uint32_t frames, uint32_t channel_begin, uint32_t channel_count, float mix_rate, float *partials, uint32_t p_offset, uint32_t p_stride) {
+hipError_t gas_launch_biquad_mix(hipStream_t stream, int mode, const gas_group_args &g, const gas_dev_state &st, uint32_t frames, uint32_t channel_begin, uint32_t channel_count, float mix_rate, float *partials, uint32_t p_offset, uint32_t p_stride, float *rows_out) {
 	if (g.n == 0) {
 		return hipSuccess;
 	}
@@ -362,16 +386,16 @@ hipError_t gas_launch_biquad_mix(hipStream_t stream, int mode, const gas_group_a
 	dim3 block(64);
 	switch (mode) {
 		case GAS_MODE_MIX_CHANNEL:
-			hipLaunchKernelGGL(k_biquad_mix<GAS_MODE_MIX_CHANNEL>, grid, block, 0, stream, g, st, frames, channel_begin, mix_rate, partials, p_offset, p_stride);
+			hipLaunchKernelGGL(k_biquad_mix<GAS_MODE_MIX_CHANNEL>, grid, block, 0, stream, g, st, frames, channel_begin, mix_rate, partials, p_offset, p_stride, rows_out);
 			break;
 		case GAS_MODE_PROCESS_FRAMES:
-			hipLaunchKernelGGL(k_biquad_mix<GAS_MODE_PROCESS_FRAMES>, grid, block, 0, stream, g, st, frames, channel_begin, mix_rate, partials, p_offset, p_stride);
+			hipLaunchKernelGGL(k_biquad_mix<GAS_MODE_PROCESS_FRAMES>, grid, block, 0, stream, g, st, frames, channel_begin, mix_rate, partials, p_offset, p_stride, rows_out);
 			break;
 		case GAS_MODE_FX_HIGHSHELF:
-			hipLaunchKernelGGL(k_biquad_mix<GAS_MODE_FX_HIGHSHELF>, grid, block, 0, stream, g, st, frames, channel_begin, mix_rate, partials, p_offset, p_stride);
+			hipLaunchKernelGGL(k_biquad_mix<GAS_MODE_FX_HIGHSHELF>, grid, block, 0, stream, g, st, frames, channel_begin, mix_rate, partials, p_offset, p_stride, rows_out);
 			break;
 		case GAS_MODE_COPY:
-			hipLaunchKernelGGL(k_biquad_mix<GAS_MODE_COPY>, grid, block, 0, stream, g, st, frames, channel_begin, mix_rate, partials, p_offset, p_stride);
+			hipLaunchKernelGGL(k_biquad_mix<GAS_MODE_COPY>, grid, block, 0, stream, g, st, frames, channel_begin, mix_rate, partials, p_offset, p_stride, rows_out);
 			break;
 		default:
 			return hipErrorInvalidValue;

@@ -405,7 +405,7 @@ struct HrtfLds {
 };
 
 template <int SQ, bool WITH_ER, bool PEAKS, bool SRC_PCM, bool XFADE>
-__device__ __forceinline__ void hrtf_body(float2 *lds_all, const uint32_t wg, const gas_group_args &g, const gas_dev_state &st, const gas_hrtf_table &tab, const float2 *__restrict__ tw, uint32_t spw, uint32_t er_R, float *__restrict__ my_partial, gas_cursor *__restrict__ cursors, const float *__restrict__ fade_env, const gas_params *__restrict__ fresh) {
+__device__ __forceinline__ void hrtf_body(float2 *lds_all, const uint32_t wg, const gas_group_args &g, const gas_dev_state &st, const gas_hrtf_table &tab, const float2 *__restrict__ tw, uint32_t spw, uint32_t er_R, float *__restrict__ my_partial, gas_cursor *__restrict__ cursors, const float *__restrict__ fade_env, const gas_params *__restrict__ fresh, gas_audio_frame *__restrict__ rows_out = nullptr) {
 	static_assert(!(WITH_ER && SRC_PCM), "the early-reflection prologue reads float rows");
 	constexpr int FQ = 2 * SQ; // F / 64
 	constexpr int HQ = 8 - SQ; // hist_len / 64
@@ -656,18 +656,25 @@ __device__ __forceinline__ void hrtf_body(float2 *lds_all, const uint32_t wg, co
 					}
 				}
 			}
+			if (rows_out) { // a stage of a general effect chain: per-source rows out, dense by group entry; no sum, no peak
 #pragma unroll
-			for (int t = 0; t < FQ; t++) {
-				accL[t] += oL[t];
-				accR[t] += oR[t];
-				pkl = fmaxf(pkl, fabsf(oL[t]));
-				pkr = fmaxf(pkr, fabsf(oR[t]));
-			}
-			pkl = wave_max(pkl);
-			pkr = wave_max(pkr);
-			if (lane == 0) {
-				g.peaks[(size_t)m.row * 2] = pkl;
-				g.peaks[(size_t)m.row * 2 + 1] = pkr;
+				for (int t = 0; t < FQ; t++) {
+					rows_out[(size_t)e * F + lane + 64 * t] = gas_audio_frame{ oL[t], oR[t] };
+				}
+			} else {
+#pragma unroll
+				for (int t = 0; t < FQ; t++) {
+					accL[t] += oL[t];
+					accR[t] += oR[t];
+					pkl = fmaxf(pkl, fabsf(oL[t]));
+					pkr = fmaxf(pkr, fabsf(oR[t]));
+				}
+				pkl = wave_max(pkl);
+				pkr = wave_max(pkr);
+				if (lane == 0) {
+					g.peaks[(size_t)m.row * 2] = pkl;
+					g.peaks[(size_t)m.row * 2 + 1] = pkr;
+				}
 			}
 		} else {
 #pragma unroll
@@ -705,6 +712,9 @@ __device__ __forceinline__ void hrtf_body(float2 *lds_all, const uint32_t wg, co
 		m = mn;
 	}
 
+	if (PEAKS && rows_out) {
+		return; // rows-out stage: nothing to sum here (wave-uniform for the whole launch)
+	}
 	if constexpr (PEAKS) {
 		// waves -> one partial mix per workgroup; each wave parks its sum in its own LDS slice
 		wave_lds_sync();
@@ -807,6 +817,64 @@ __global__ __launch_bounds__(WAVES * 64, GAS_HRTF_WAVES_PER_SIMD) void k_hrtf_ol
 	}
 }
 
+// One HRTF stage of a general effect chain: stereo rows in (mono downmix inside), per-source stereo rows out.
+template <int SQ, bool XFADE>
+__global__ __launch_bounds__(WAVES * 64, GAS_HRTF_WAVES_PER_SIMD) void k_hrtf_rows(gas_group_args g, gas_dev_state st, gas_hrtf_table tab, const float2 *__restrict__ tw, uint32_t spw, gas_audio_frame *__restrict__ rows_out) {
+	__shared__ float2 lds_all[HrtfLds<SQ, true>::TOTAL_F2];
+	hrtf_body<SQ, false, true, false, XFADE>(lds_all, blockIdx.x, g, st, tab, tw, spw, 0, nullptr, nullptr, nullptr, nullptr, rows_out);
+}
+
+// The last stage of a general chain left per-source rows: add them into this workgroup's partial mix and take each
+// source's peak (audio_spatializer.cpp:449-461).  Wave = source, lane = frame, like k_er_only without the taps.
+template <int FQ>
+__global__ __launch_bounds__(WAVES * 64) void k_rows_accumulate(gas_group_args g, uint32_t spw, float *__restrict__ partials, uint32_t p_offset) {
+	constexpr uint32_t F = FQ * 64;
+	__shared__ float red_all[WAVES * F * 2];
+	const int lane = threadIdx.x & 63;
+	const int wave = threadIdx.x >> 6;
+	float accL[FQ], accR[FQ];
+#pragma unroll
+	for (int t = 0; t < FQ; t++) {
+		accL[t] = 0.0f;
+		accR[t] = 0.0f;
+	}
+	const uint32_t first = (blockIdx.x * WAVES + wave) * spw;
+	const uint32_t last = first + spw < g.n ? first + spw : g.n;
+	for (uint32_t e = first; e < last; e++) {
+		const uint32_t row = g.rows ? g.rows[e] : e; // where this source's peak goes
+		float pkl = 0.0f, pkr = 0.0f;
+#pragma unroll
+		for (int q = 0; q < FQ; q++) {
+			const gas_audio_frame fr = g.src[(size_t)e * F + lane + 64 * q]; // dense rows of the previous stage
+			accL[q] += fr.left;
+			accR[q] += fr.right;
+			pkl = fmaxf(pkl, fabsf(fr.left));
+			pkr = fmaxf(pkr, fabsf(fr.right));
+		}
+		pkl = wave_max(pkl);
+		pkr = wave_max(pkr);
+		if (lane == 0) {
+			g.peaks[(size_t)row * 2] = pkl;
+			g.peaks[(size_t)row * 2 + 1] = pkr;
+		}
+	}
+	float *red = red_all + wave * F * 2;
+#pragma unroll
+	for (int t = 0; t < FQ; t++) {
+		*reinterpret_cast<float2 *>(red + (lane + 64 * t) * 2) = make_float2(accL[t], accR[t]);
+	}
+	__syncthreads();
+	float *my_partial = partials + ((size_t)p_offset + blockIdx.x) * (F * 2);
+	for (int idx = threadIdx.x; idx < (int)(F * 2); idx += WAVES * 64) {
+		float sacc = 0.0f;
+#pragma unroll
+		for (int w = 0; w < WAVES; w++) {
+			sacc += red_all[w * F * 2 + idx];
+		}
+		my_partial[idx] = sacc;
+	}
+}
+
 // HRIR [dirs][2][taps] -> lane-major half-spectra table (see issue_spectra), one wave per (direction, ear),
 // scaled by 1/512 so the inverse transform needs no normalisation.
 __global__ __launch_bounds__(64) void k_hrtf_table(const float *__restrict__ hrir, uint32_t dirs, uint32_t taps, const float2 *__restrict__ tw, float4 *__restrict__ spec) {
@@ -844,7 +912,7 @@ __global__ __launch_bounds__(64) void k_hrtf_table(const float *__restrict__ hri
 
 // The chain [EARLY_REFLECTIONS] alone: stereo out, lane = frame, wave = source.
 template <int FQ>
-__global__ __launch_bounds__(WAVES * 64) void k_er_only(gas_group_args g, gas_dev_state st, uint32_t spw, uint32_t er_R, float *__restrict__ partials, uint32_t p_offset) {
+__global__ __launch_bounds__(WAVES * 64) void k_er_only(gas_group_args g, gas_dev_state st, uint32_t spw, uint32_t er_R, float *__restrict__ partials, uint32_t p_offset, gas_audio_frame *__restrict__ rows_out) {
 	constexpr uint32_t F = FQ * 64;
 	__shared__ float red_all[WAVES * F * 2];
 	const int lane = threadIdx.x & 63;
@@ -881,18 +949,27 @@ __global__ __launch_bounds__(WAVES * 64) void k_er_only(gas_group_args g, gas_de
 				yl = yl + gk * xp.left;
 				yr = yr + gk * xp.right;
 			}
-			accL[q] += yl;
-			accR[q] += yr;
-			pkl = fmaxf(pkl, fabsf(yl));
-			pkr = fmaxf(pkr, fabsf(yr));
+			if (rows_out) { // a stage of a general effect chain: dense per-source rows, no sum, no peak
+				rows_out[(size_t)e * F + f] = gas_audio_frame{ yl, yr };
+			} else {
+				accL[q] += yl;
+				accR[q] += yr;
+				pkl = fmaxf(pkl, fabsf(yl));
+				pkr = fmaxf(pkr, fabsf(yr));
+			}
 		}
 		pkl = wave_max(pkl);
 		pkr = wave_max(pkr);
 		if (lane == 0) {
 			st.er_pos[slot] = (er_pos + F) & (er_R - 1);
-			g.peaks[(size_t)row * 2] = pkl;
-			g.peaks[(size_t)row * 2 + 1] = pkr;
+			if (!rows_out) {
+				g.peaks[(size_t)row * 2] = pkl;
+				g.peaks[(size_t)row * 2 + 1] = pkr;
+			}
 		}
+	}
+	if (rows_out) {
+		return; // wave-uniform for the whole launch
 	}
 	float *red = red_all + wave * F * 2;
 #pragma unroll
@@ -1005,7 +1082,7 @@ hipError_t gas_launch_hrtf_ols(hipStream_t stream, bool with_er, bool crossfade,
 	return hipGetLastError();
 }
 
-hipError_t gas_launch_er_only(hipStream_t stream, const gas_group_args &g, const gas_dev_state &st, uint32_t frames, uint32_t er_ring_frames, float *partials, uint32_t p_offset, uint32_t p_stride) {
+hipError_t gas_launch_er_only(hipStream_t stream, const gas_group_args &g, const gas_dev_state &st, uint32_t frames, uint32_t er_ring_frames, float *partials, uint32_t p_offset, uint32_t p_stride, gas_audio_frame *rows_out) {
 	(void)p_stride;
 	if (g.n == 0) {
 		return hipSuccess;
@@ -1015,16 +1092,69 @@ hipError_t gas_launch_er_only(hipStream_t stream, const gas_group_args &g, const
 	dim3 grid(wgs), block(WAVES * 64);
 	switch (frames / 64) {
 		case 2:
-			hipLaunchKernelGGL((k_er_only<2>), grid, block, 0, stream, g, st, spw, er_ring_frames, partials, p_offset);
+			hipLaunchKernelGGL((k_er_only<2>), grid, block, 0, stream, g, st, spw, er_ring_frames, partials, p_offset, rows_out);
 			break;
 		case 4:
-			hipLaunchKernelGGL((k_er_only<4>), grid, block, 0, stream, g, st, spw, er_ring_frames, partials, p_offset);
+			hipLaunchKernelGGL((k_er_only<4>), grid, block, 0, stream, g, st, spw, er_ring_frames, partials, p_offset, rows_out);
 			break;
 		case 6:
-			hipLaunchKernelGGL((k_er_only<6>), grid, block, 0, stream, g, st, spw, er_ring_frames, partials, p_offset);
+			hipLaunchKernelGGL((k_er_only<6>), grid, block, 0, stream, g, st, spw, er_ring_frames, partials, p_offset, rows_out);
 			break;
 		case 8:
-			hipLaunchKernelGGL((k_er_only<8>), grid, block, 0, stream, g, st, spw, er_ring_frames, partials, p_offset);
+			hipLaunchKernelGGL((k_er_only<8>), grid, block, 0, stream, g, st, spw, er_ring_frames, partials, p_offset, rows_out);
+			break;
+		default:
+			return hipErrorInvalidValue;
+	}
+	return hipGetLastError();
+}
+
+hipError_t gas_launch_hrtf_rows(hipStream_t stream, bool crossfade, const gas_group_args &g, const gas_dev_state &st, const gas_hrtf_table &tab, const float2 *twiddles, uint32_t frames, gas_audio_frame *rows_out) {
+	if (g.n == 0) {
+		return hipSuccess;
+	}
+	uint32_t spw = 1;
+	const uint32_t wgs = gas_hrtf_partials(g.n, &spw);
+	dim3 grid(wgs), block(WAVES * 64);
+#define GAS_ROWS_CASE(SQv)                                                                                              \
+	case SQv:                                                                                                           \
+		if (crossfade) {                                                                                                \
+			hipLaunchKernelGGL((k_hrtf_rows<SQv, true>), grid, block, 0, stream, g, st, tab, twiddles, spw, rows_out);  \
+		} else {                                                                                                        \
+			hipLaunchKernelGGL((k_hrtf_rows<SQv, false>), grid, block, 0, stream, g, st, tab, twiddles, spw, rows_out); \
+		}                                                                                                               \
+		break;
+	switch (frames / 128) {
+		GAS_ROWS_CASE(1)
+		GAS_ROWS_CASE(2)
+		GAS_ROWS_CASE(3)
+		GAS_ROWS_CASE(4)
+		default:
+			return hipErrorInvalidValue;
+	}
+#undef GAS_ROWS_CASE
+	return hipGetLastError();
+}
+
+hipError_t gas_launch_rows_accumulate(hipStream_t stream, const gas_group_args &g, uint32_t frames, float *partials, uint32_t p_offset) {
+	if (g.n == 0) {
+		return hipSuccess;
+	}
+	uint32_t spw = 1;
+	const uint32_t wgs = gas_hrtf_partials(g.n, &spw);
+	dim3 grid(wgs), block(WAVES * 64);
+	switch (frames / 64) {
+		case 2:
+			hipLaunchKernelGGL((k_rows_accumulate<2>), grid, block, 0, stream, g, spw, partials, p_offset);
+			break;
+		case 4:
+			hipLaunchKernelGGL((k_rows_accumulate<4>), grid, block, 0, stream, g, spw, partials, p_offset);
+			break;
+		case 6:
+			hipLaunchKernelGGL((k_rows_accumulate<6>), grid, block, 0, stream, g, spw, partials, p_offset);
+			break;
+		case 8:
+			hipLaunchKernelGGL((k_rows_accumulate<8>), grid, block, 0, stream, g, spw, partials, p_offset);
 			break;
 		default:
 			return hipErrorInvalidValue;

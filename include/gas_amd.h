@@ -144,6 +144,10 @@ const char *gas_last_device_error(gas_ctx *ctx);
 
 /* ---- per-playback state: _instantiate_playback_data (audio_spatializer.cpp:69),
  * deferred delete (audio_spatializer.cpp:538-547) ------------------------ */
+/* GAS_KIND_EFFECT chains (audio_spatializer_effect.cpp:33-77): up to GAS_MAX_EFFECTS of GAS_FX_*, in processing
+ * order, with at most one EARLY_REFLECTIONS (needs cfg.er_ring_frames) and one HRTF per playback.  [], [HIGHSHELF],
+ * [ER], [HRTF] and [ER, HRTF] run as one fused kernel; any other order runs one launch per effect through ping-pong
+ * row buffers, as the reference's loop does.  Everything else: GAS_ERR_UNSUPPORTED_CHAIN. */
 int gas_source_alloc(gas_ctx *ctx, int kind, const int32_t *effects, uint32_t n_effects, uint32_t *out_slot);
 int gas_source_free(gas_ctx *ctx, uint32_t slot); /* takes effect at the next block boundary */
 int gas_source_reset(gas_ctx *ctx, uint32_t slot); /* zero the slot's DSP state (a restarted playback) */

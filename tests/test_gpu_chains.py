@@ -1,0 +1,116 @@
+"""effect chains without a fused kernel run staged (one launch per effect through ping-pong row
+buffers, then k_rows_accumulate) and must match the oracle's ping-pong chain (audio_spatializer_effect.cpp:52-76)."""
+import numpy as np
+import pytest
+
+from helpers import TOL, rel_rms
+
+pytestmark = pytest.mark.gpu
+
+HS, ER, HRTF = 1, 2, 3
+
+
+def _hrir(dirs=32, seed=5):
+    from godot_audio_spatializer_amd import synth
+
+    return synth.synthetic_hrir(np.random.default_rng(seed), dirs=dirs)
+
+
+@pytest.mark.parametrize(
+    "chain,frames",
+    [
+        ((HS, HRTF), 512),
+        ((HRTF, HS), 512),
+        ((HS, HS), 512),
+        ((ER, HS), 256),
+        ((HS, ER), 256),
+        ((HS, ER, HRTF), 256),
+        ((ER, HRTF, HS), 256),
+        ((HS, ER, HRTF, HS), 128),
+        ((HRTF, ER), 256),
+    ],
+)
+def test_staged_chain_matches_oracle(gas, ob, chain, frames):
+    from test_gpu_parity import run_pair
+
+    ring = 4096 if ER in chain else 0
+    hrir = _hrir() if HRTF in chain else None
+    run_pair(gas, ob, gas.capi.KIND_EFFECT, chain, 70, frames, 10, hrir=hrir, ring=ring, dirs=32, redraw_every=3)
+
+
+def test_staged_chain_crossfade(gas, ob):
+    from test_gpu_parity import run_pair
+
+    run_pair(gas, ob, gas.capi.KIND_EFFECT, (HS, HRTF), 45, 512, 8, hrir=_hrir(), dirs=32, redraw_every=2, flags=gas.capi.FLAG_HRTF_CROSSFADE)
+
+
+def test_mixed_chains_in_one_callback(gas, ob):
+    """Fused and staged chains interleaved in one callback: the mix is the sum of the per-chain oracles' mixes and
+    every source's peak lands on its own row."""
+    from godot_audio_spatializer_amd import synth
+
+    rng = np.random.default_rng(11)
+    frames, ring = 256, 4096
+    hrir = _hrir()
+    chains = [(HRTF,), (HS, HRTF), (ER, HRTF), (HRTF, HS), (HS,), (HS, ER), (HS, HRTF)]
+    per = [9, 13, 7, 11, 5, 8, 6]
+    n = sum(per)
+    ctx = gas.SpatializerContext(max_sources=n, frames=frames, er_ring_frames=ring)
+    ctx.hrtf_load(hrir)
+    slots, oras, owner = [], [], []
+    for k, (ch, m) in enumerate(zip(chains, per)):
+        slots.append(ctx.source_alloc_many(m, gas.capi.KIND_EFFECT, ch))
+        oras.append(ob.BatchOracle(ob.KIND_EFFECT, m, frames, chain=ch, hrir=hrir, er_ring_frames=ring))
+        owner += [k] * m
+    slots = np.concatenate(slots)
+    owner = np.asarray(owner)
+    perm = rng.permutation(n)  # interleave the chains in the callback's order
+    for b in range(8):
+        if b % 3 == 0:
+            p = synth.draw_params(rng, n, dirs=32, ring_frames=ring, frames=frames)
+            ctx.params_publish_batch(slots, p)
+        src = synth.draw_sources(rng, n, frames)
+        mix, peaks = ctx.process_block(src[perm], slots[perm])
+        ref = np.zeros((frames, 2))
+        rpeaks = np.zeros((n, 2), np.float32)
+        for k, o in enumerate(oras):
+            sel = owner == k
+            _, pk, m64 = o.block(p[sel].astype(ob.PARAMS_DTYPE), src[sel], want64=True)
+            ref += m64[0]
+            rpeaks[sel] = pk
+        assert rel_rms(mix[0], ref) <= TOL, f"block {b}"
+        np.testing.assert_allclose(peaks, rpeaks[perm], rtol=2e-5, atol=1e-7)
+    ctx.close()
+
+
+def test_staged_chain_single_instance_entry(gas, ob):
+    """gas_process_frames_1 on a staged chain (the per-instance plugin call, audio_spatializer.h:146)."""
+    from godot_audio_spatializer_amd import synth
+
+    rng = np.random.default_rng(3)
+    frames = 512
+    hrir = _hrir()
+    ctx = gas.SpatializerContext(max_sources=4, frames=frames)
+    ctx.hrtf_load(hrir)
+    (slot,) = ctx.source_alloc_many(1, gas.capi.KIND_EFFECT, (HS, HRTF))
+    ora = ob.BatchOracle(ob.KIND_EFFECT, 1, frames, chain=(HS, HRTF), hrir=hrir)
+    for b in range(4):
+        p = synth.draw_params(rng, 1, dirs=32, frames=frames)
+        ctx.params_publish_batch(np.asarray([slot], np.uint32), p)
+        src = synth.draw_sources(rng, 1, frames)
+        out = ctx.process_frames_1(slot, src[0])
+        _, _, m64 = ora.block(p.astype(ob.PARAMS_DTYPE), src, want64=True)
+        assert rel_rms(out, m64[0]) <= TOL
+    ctx.close()
+
+
+def test_unsupported_chains_still_fail_loudly(gas):
+    K = gas.capi
+    ctx = gas.SpatializerContext(max_sources=4, frames=256, er_ring_frames=0)
+    with pytest.raises(gas.GasError):
+        ctx.source_alloc_many(1, K.KIND_EFFECT, (HS, ER))  # needs the ring
+    with pytest.raises(gas.GasError):
+        ctx.source_alloc_many(1, K.KIND_EFFECT, (HRTF, HS, HRTF))  # one HRTF history per playback
+    with pytest.raises(gas.GasError):
+        ctx.source_alloc_many(1, K.KIND_EFFECT, (HS, 9))
+    ctx.close()

@@ -51,9 +51,11 @@ def test_error_paths_return_codes_and_zero_the_mix(gas):
         ctx.params_publish(s1, synth.draw_params(rng, 1, dirs=8)[0])
         assert call(src, np.array([s1], np.uint32), 1, 512) == -5 and not out.any()
         # unsupported chains / kinds
-        fx = (C.c_int32 * 2)(gas.capi.FX_HRTF, gas.capi.FX_HIGHSHELF)
+        fx = (C.c_int32 * 3)(gas.capi.FX_HRTF, gas.capi.FX_HIGHSHELF, gas.capi.FX_HRTF)
         slot = C.c_uint32()
-        assert lib.gas_source_alloc(h, gas.capi.KIND_EFFECT, fx, 2, C.byref(slot)) == -6
+        assert lib.gas_source_alloc(h, gas.capi.KIND_EFFECT, fx, 3, C.byref(slot)) == -6  # one HRTF history per playback
+        fx5 = (C.c_int32 * 5)(*([gas.capi.FX_HIGHSHELF] * 5))
+        assert lib.gas_source_alloc(h, gas.capi.KIND_EFFECT, fx5, 5, C.byref(slot)) != 0  # more effects than GAS_MAX_EFFECTS
         assert lib.gas_source_alloc(h, 7, None, 0, C.byref(slot)) == -1
         fx1 = (C.c_int32 * 1)(gas.capi.FX_EARLY_REFLECTIONS)
         assert lib.gas_source_alloc(h, gas.capi.KIND_EFFECT, fx1, 1, C.byref(slot)) == -6  # context has no ER ring

@@ -1,0 +1,44 @@
+"""Dev aid: callback time of fused vs staged effect chains for N sources."""
+import sys
+
+import numpy as np
+
+sys.path.insert(0, ".")
+import torch  # noqa: E402
+
+import godot_audio_spatializer_amd as gas  # noqa: E402
+from godot_audio_spatializer_amd import synth  # noqa: E402
+
+HS, ER, HRTF = 1, 2, 3
+
+
+def run(chain, n, frames=512, steps=300):
+    rng = np.random.default_rng(0)
+    ring = 4096 if ER in chain else 0
+    ctx = gas.SpatializerContext(max_sources=n, frames=frames, er_ring_frames=ring)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    ctx.hrtf_load(synth.synthetic_hrir(rng, dirs=1024))
+    slots = ctx.source_alloc_many(n, gas.capi.KIND_EFFECT, chain)
+    p = synth.draw_params(rng, n, dirs=1024, ring_frames=max(ring, 2 * frames), frames=frames)
+    ctx.params_publish_batch(slots, p)
+    src = torch.rand(n, frames, 2, device="cuda") - 0.5
+    out = torch.zeros(1, frames, 2, device="cuda")
+    pk = torch.zeros(n, 2, device="cuda")
+    for _ in range(10):
+        ctx.process_block_raw(src.data_ptr(), slots, n, frames, out.data_ptr(), pk.data_ptr(), 1)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(steps):
+        ctx.process_block_raw(src.data_ptr(), None, n, frames, out.data_ptr(), pk.data_ptr(), 1)
+    e1.record()
+    torch.cuda.synchronize()
+    us = 1e3 * e0.elapsed_time(e1) / steps
+    print(f"chain {str(chain):14s} n={n:6d} F={frames}: {us:7.1f} us/callback")
+    ctx.close()
+
+
+if __name__ == "__main__":
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
+    for chain in ((HRTF,), (HS, HRTF), (HRTF, HS), (HS,), (HS, HS), (ER, HRTF), (HS, ER, HRTF), (ER, HS)):
+        run(chain, n, 256 if ER in chain else 512)
