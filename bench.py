@@ -129,6 +129,8 @@ def main():
     ap.add_argument("--profile-every", type=int, default=4, help="bracket the dominant kernel of every Nth step with HIP events (markers cost ~2 us each)")
     ap.add_argument("--reduce-bucket", type=int, default=8, help="callbacks per cross-GPU reduce (N > 1)")
     ap.add_argument("--crossfade", action="store_true", help="GAS_FLAG_HRTF_CROSSFADE: blend old/new HRIRs when a source's direction changes (SURVEY 8f#4)")
+    ap.add_argument("--direction-order", action="store_true", help="GAS_FLAG_DIRECTION_ORDER: let the library group sources by HRIR direction (device sort per publish)")
+    ap.add_argument("--presorted-directions", action="store_true", help="diagnostic: publish parameters whose HRIR directions are already grouped in callback order")
     ap.add_argument("--exact-peaks", action="store_true", help="per-source inverse FFTs for every source (exact peak of every source)")
     args = ap.parse_args()
 
@@ -171,6 +173,8 @@ def main():
     flags = 0 if args.exact_peaks else gas.capi.FLAG_PEAKS_DRAINING_ONLY
     if args.crossfade:
         flags |= gas.capi.FLAG_HRTF_CROSSFADE
+    if args.direction_order:
+        flags |= gas.capi.FLAG_DIRECTION_ORDER
     ctx = gas.SpatializerContext(max_sources=n_local, frames=frames, channel_count=1, er_ring_frames=ring, device=local_rank, flags=flags)
     stream = torch.cuda.current_stream()
     ctx.set_stream(stream.cuda_stream)
@@ -188,6 +192,8 @@ def main():
     psets = []
     for _ in range(2):
         p = synth.draw_params(prng, n_local, dirs=args.dirs, ring_frames=max(ring, 2 * frames), frames=frames)
+        if args.presorted_directions:
+            p["hrtf_dir"] = np.sort(p["hrtf_dir"])
         psets.append(torch.from_numpy(p.view(np.uint8).reshape(n_local, 128).copy()).cuda())
     ctx.params_publish_batch(slots, synth.draw_params(prng, n_local, dirs=args.dirs, ring_frames=max(ring, 2 * frames), frames=frames))
 

@@ -24,6 +24,7 @@ MEM_HOST = 0
 MEM_DEVICE = 1
 FLAG_PEAKS_DRAINING_ONLY = 1
 FLAG_HRTF_CROSSFADE = 2
+FLAG_DIRECTION_ORDER = 4
 
 STATUS = {
     0: "GAS_OK",

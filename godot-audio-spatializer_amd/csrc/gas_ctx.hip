@@ -5,6 +5,8 @@
 // There is NO CPU fallback: every entry needs a HIP device and fails with GAS_ERR_NO_DEVICE /
 // GAS_ERR_DEVICE otherwise.
 #include <algorithm>
+#include <atomic>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 
@@ -88,6 +90,10 @@ struct gas_ctx {
 	uint32_t *d_slots_rows = nullptr; // the caller's list in row order (device-side parameter publication)
 	uint32_t cached_n = UINT32_MAX;
 	uint64_t groups_gen = 0; // bumped whenever build_groups re-sorts a slot list
+	std::atomic<uint64_t> params_gen{ 1 }; // bumped by every call that can change a source's HRIR direction
+	uint32_t *d_order = nullptr; // [max_sources] direction order of the frequency-domain HRTF groups (k_dir_order)
+	uint64_t order_groups_gen = UINT64_MAX, order_params_gen = 0; // what d_order was built from
+	bool order_ok[G_COUNT] = {}; // d_order holds this group's order
 	uint64_t stream_groups_gen = UINT64_MAX; // groups_gen the stream path's cached list corresponds to
 	bool cached_identity_rows = true;
 	Group groups[G_COUNT];
@@ -295,7 +301,7 @@ int ensure_partials(gas_ctx *c, uint32_t rows) {
 }
 
 // Device work of one callback over already-grouped entries.
-int run_groups(gas_ctx *c, const gas_audio_frame *d_src, const uint32_t *d_slots, const uint32_t *d_rows, const Group *groups, const std::vector<ChainRange> &ranges, uint32_t n_total, gas_audio_frame *d_out, float *d_peaks, uint32_t channel_begin, uint32_t channel_count, int force_mode) {
+int run_groups(gas_ctx *c, const gas_audio_frame *d_src, const uint32_t *d_slots, const uint32_t *d_rows, const Group *groups, const std::vector<ChainRange> &ranges, uint32_t n_total, gas_audio_frame *d_out, float *d_peaks, uint32_t channel_begin, uint32_t channel_count, int force_mode, bool use_order = false) {
 	const uint32_t F = c->cfg.frames;
 	uint32_t pcount[G_COUNT];
 	plan_partials(groups, ranges, pcount);
@@ -393,7 +399,24 @@ int run_groups(gas_ctx *c, const gas_audio_frame *d_src, const uint32_t *d_slots
 					g_pk.slots = nullptr;
 					g_pk.slot_base = groups[fd_gt + 1].slot_base;
 				}
-				e = gas_launch_hrtf_ols(c->stream, fd_gt == G_FX_ER_HRTF, (c->cfg.flags & GAS_FLAG_HRTF_CROSSFADE) != 0, g_fd, g_pk, c->st, c->tab, c->d_tw, F, c->hist_len, c->cfg.er_ring_frames, c->d_partials, p_off, fd_gt == G_FX_HRTF && c->fused_streams ? c->d_cursors : nullptr, c->d_fade_env, fd_gt == G_FX_HRTF ? c->fresh_for_launch : nullptr);
+				// GAS_FLAG_DIRECTION_ORDER: direction order of the frequency-domain group, rebuilt when the
+				// callback's list or any parameter changed, else reused.  Only when directions repeat within a segment.
+				const gas_params *fresh = fd_gt == G_FX_HRTF ? c->fresh_for_launch : nullptr;
+				if (use_order && (c->cfg.flags & GAS_FLAG_DIRECTION_ORDER) != 0 && g_fd.n >= GAS_DIR_ORDER_MIN_SOURCES && (c->cfg.flags & GAS_FLAG_HRTF_CROSSFADE) == 0 && gas_dir_order_supported(c->tab.dirs)) {
+					const uint32_t seg = g_fd.n < GAS_DIR_ORDER_SEGMENT ? g_fd.n : GAS_DIR_ORDER_SEGMENT;
+					if (seg >= 2 * c->tab.dirs) {
+						if (!c->d_order) {
+							GAS_HIP(c, hipMalloc(&c->d_order, (size_t)c->cfg.max_sources * sizeof(uint32_t)));
+						}
+						uint32_t *ord = c->d_order + groups[fd_gt].offset;
+						if (!c->order_ok[fd_gt]) {
+							GAS_HIP(c, gas_launch_dir_order(c->stream, g_fd, c->st.params, fresh, c->tab.dirs, ord));
+							c->order_ok[fd_gt] = true;
+						}
+						g_fd.order = ord;
+					}
+				}
+				e = gas_launch_hrtf_ols(c->stream, fd_gt == G_FX_ER_HRTF, (c->cfg.flags & GAS_FLAG_HRTF_CROSSFADE) != 0, g_fd, g_pk, c->st, c->tab, c->d_tw, F, c->hist_len, c->cfg.er_ring_frames, c->d_partials, p_off, fd_gt == G_FX_HRTF && c->fused_streams ? c->d_cursors : nullptr, c->d_fade_env, fresh);
 			} break;
 			case G_FX_GENERIC: {
 				// audio_spatializer_effect.cpp:52-76 on the device: effect j reads the previous stage's rows and writes
@@ -698,6 +721,7 @@ void gas_ctx_destroy(gas_ctx *c) {
 	(void)hipFree(c->d_src);
 	(void)hipFree(c->d_chain[0]);
 	(void)hipFree(c->d_chain[1]);
+	(void)hipFree(c->d_order);
 	(void)hipFree(c->d_out);
 	(void)hipFree(c->d_peaks);
 	(void)hipFree(c->d_partials);
@@ -939,6 +963,7 @@ int gas_params_publish(gas_ctx *c, uint32_t slot, const gas_params *params) {
 	}
 	std::lock_guard<std::mutex> lk(c->params_mu);
 	c->stream_params_touched = true;
+	c->params_gen++;
 	c->h_params[slot] = *params;
 	if (!c->dirty_flag[slot]) {
 		c->dirty_flag[slot] = 1;
@@ -963,6 +988,7 @@ int gas_params_publish_batch(gas_ctx *c, const uint32_t *slots, const gas_params
 		}
 		std::lock_guard<std::mutex> lk(c->params_mu);
 		c->stream_params_touched = true;
+		c->params_gen++;
 		for (uint32_t i = 0; i < n; i++) {
 			const uint32_t s = slots[i];
 			c->h_params[s] = params[i];
@@ -974,6 +1000,7 @@ int gas_params_publish_batch(gas_ctx *c, const uint32_t *slots, const gas_params
 		}
 		return GAS_OK;
 	}
+	c->params_gen++;
 	// Device-resident parameter rows (e.g. produced by a parameter kernel): scatter on the stream.
 	// slots == NULL addresses the slot list of the last gas_process_block, in its row order.
 	GAS_HIP(c, hipSetDevice(c->cfg.device));
@@ -1253,8 +1280,6 @@ int gas_process_block_streams(gas_ctx *c, const uint32_t *slots, uint32_t n, uin
 			if (c->d_src) {
 				(void)hipStreamSynchronize(c->stream);
 				(void)hipFree(c->d_src);
-	(void)hipFree(c->d_chain[0]);
-	(void)hipFree(c->d_chain[1]);
 				c->d_src = nullptr;
 				c->d_src_frames = 0;
 			}
@@ -1325,6 +1350,7 @@ int gas_hrtf_load(gas_ctx *c, const float *hrir, uint32_t dirs, uint32_t taps) {
 	(void)hipFree(d_hrir);
 	if (rc == GAS_OK) {
 		c->tab.dirs = dirs;
+		c->params_gen++;
 	}
 	return rc;
 }
@@ -1367,9 +1393,15 @@ int gas_process_block(gas_ctx *c, const gas_audio_frame *src, const uint32_t *sl
 	if (needs_hrtf(c)) {
 		return fail(GAS_ERR_NO_HRTF);
 	}
+	const uint64_t pgen = c->params_gen.load(); // read before the snapshot: a publish racing with it re-sorts next time
 	rc = flush_params(c); // one snapshot per callback (audio_spatializer.cpp:328)
 	if (rc != GAS_OK) {
 		return fail(rc);
+	}
+	if (c->order_groups_gen != c->groups_gen || c->order_params_gen != pgen) {
+		std::memset(c->order_ok, 0, sizeof(c->order_ok));
+		c->order_groups_gen = c->groups_gen;
+		c->order_params_gen = pgen;
 	}
 
 	const gas_audio_frame *d_src = src;
@@ -1380,8 +1412,6 @@ int gas_process_block(gas_ctx *c, const gas_audio_frame *src, const uint32_t *sl
 		if (need > c->d_src_frames) {
 			if (c->d_src) {
 				(void)hipFree(c->d_src);
-	(void)hipFree(c->d_chain[0]);
-	(void)hipFree(c->d_chain[1]);
 				c->d_src = nullptr;
 				c->d_src_frames = 0;
 			}
@@ -1416,7 +1446,7 @@ int gas_process_block(gas_ctx *c, const gas_audio_frame *src, const uint32_t *sl
 			}
 		}
 	}
-	rc = run_groups(c, d_src, c->d_slots, c->cached_identity_rows ? nullptr : c->d_rows, c->groups, c->chain_ranges, n, d_out, d_peaks, 0, C, -1);
+	rc = run_groups(c, d_src, c->d_slots, c->cached_identity_rows ? nullptr : c->d_rows, c->groups, c->chain_ranges, n, d_out, d_peaks, 0, C, -1, true);
 	c->fresh_for_launch = nullptr;
 	if (rc != GAS_OK) {
 		return fail(rc);
@@ -1489,8 +1519,6 @@ static int process_one(gas_ctx *c, uint32_t slot, int channel, bool mix_channel,
 	if (c->d_src_frames < F) {
 		if (c->d_src) {
 			(void)hipFree(c->d_src);
-	(void)hipFree(c->d_chain[0]);
-	(void)hipFree(c->d_chain[1]);
 			c->d_src = nullptr;
 			c->d_src_frames = 0;
 		}

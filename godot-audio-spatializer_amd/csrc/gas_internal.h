@@ -52,6 +52,7 @@ struct gas_group_args {
 	uint32_t slot_base;
 	uint32_t n;
 	float *peaks; // [n_rows_total][2]
+	const uint32_t *order = nullptr; // [n] k_hrtf_ols only: processing order (entries grouped by HRIR direction), or nullptr = entry order
 };
 
 enum gas_biquad_mode {
@@ -92,4 +93,8 @@ hipError_t gas_launch_scatter_params(hipStream_t stream, gas_params *table, cons
 hipError_t gas_launch_calc_spatialization(hipStream_t stream, const gas_spatializer3d_config *cfgs, const uint32_t *cfg_index, const gas_source_pose *poses, const gas_listener *listeners, uint32_t n_listeners, const uint32_t *slots, uint32_t n, gas_params *table, uint8_t *was_further, gas_params *out_params);
 hipError_t gas_launch_sample_sources(hipStream_t stream, gas_cursor *cursors, const uint32_t *slots, uint32_t n, uint32_t frames, const float *fade_env, gas_audio_frame *rows);
 hipError_t gas_launch_noop(hipStream_t stream); // event-timer calibration
+#define GAS_DIR_ORDER_SEGMENT 8192
+#define GAS_DIR_ORDER_MIN_SOURCES 512
+bool gas_dir_order_supported(uint32_t dirs);
+hipError_t gas_launch_dir_order(hipStream_t stream, const gas_group_args &g, const gas_params *params, const gas_params *fresh, uint32_t dirs, uint32_t *order);
 hipError_t gas_launch_zero_slot(hipStream_t stream, const gas_dev_state &st, uint32_t slot, uint32_t hist_len, uint32_t er_ring_frames);

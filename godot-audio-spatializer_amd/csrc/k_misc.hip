@@ -93,10 +93,145 @@ __global__ void k_zero_slot(gas_dev_state st, uint32_t slot, uint32_t hist_len, 
 __global__ void k_noop() {
 }
 
+// Direction order of a launch group's HRTF sources: order[k] = group entry, such that entries with
+// the same HRIR direction are adjacent.  k_hrtf_ols adds the windows of a run of equal-direction sources in the time
+// domain and pays one FFT and one table row for the run.  The order is an optimisation only (any permutation is
+// correct), so it is built per SEGMENT of DIR_SEG entries: one workgroup, no cross-workgroup step, one launch.
+//
+// Stable counting sort without atomics (bitwise-reproducible order => bitwise-reproducible sums): wave w owns the
+// contiguous entries [w*512, w*512+512) of the segment and walks them 64 at a time; lanes with equal keys find each
+// other with one ballot per key bit; hist[w][key] counts the wave's entries per key in order; a per-key prefix over
+// the 16 waves and one exclusive scan over the keys give every entry its destination.
+constexpr int DIR_SEG = GAS_DIR_ORDER_SEGMENT;
+constexpr int DIR_WAVES = 16;
+constexpr int DIR_ROUNDS = DIR_SEG / (DIR_WAVES * 64);
+constexpr int DIR_KEY_BITS = 12; // dirs <= 4096
+
+__global__ __launch_bounds__(DIR_WAVES * 64) void k_dir_order(gas_group_args g, const gas_params *__restrict__ params, const gas_params *__restrict__ fresh, uint32_t dirs, uint32_t *__restrict__ order) {
+	extern __shared__ uint32_t dir_lds[];
+	uint32_t *base = dir_lds; // [dirs] totals, then exclusive scan
+	uint16_t *hist = reinterpret_cast<uint16_t *>(dir_lds + dirs); // [DIR_WAVES][dirs]
+	const int lane = threadIdx.x & 63;
+	const int wave = threadIdx.x >> 6;
+	const uint32_t seg0 = blockIdx.x * DIR_SEG;
+	for (uint32_t i = threadIdx.x; i < DIR_WAVES * dirs / 2; i += DIR_WAVES * 64) {
+		reinterpret_cast<uint32_t *>(hist)[i] = 0;
+	}
+	// every load is unconditional (out-of-range lanes read entry 0 and are masked afterwards) and the three
+	// dependent levels are issued round by round, so the wave waits for three round trips, not 3 x DIR_ROUNDS
+	uint32_t key[DIR_ROUNDS], slot[DIR_ROUNDS], row[DIR_ROUNDS];
+	bool valid[DIR_ROUNDS];
+#pragma unroll
+	for (int r = 0; r < DIR_ROUNDS; r++) {
+		const uint32_t e = seg0 + wave * (DIR_ROUNDS * 64) + r * 64 + lane;
+		valid[r] = e < g.n;
+		const uint32_t ec = valid[r] ? e : 0;
+		slot[r] = g.slots ? g.slots[ec] : g.slot_base + ec;
+		row[r] = g.rows ? g.rows[ec] : ec;
+	}
+#pragma unroll
+	for (int r = 0; r < DIR_ROUNDS; r++) {
+		const gas_params *P = fresh ? fresh + row[r] : params + slot[r];
+		const uint32_t d = P->hrtf_dir;
+		key[r] = valid[r] && d < dirs ? d : 0; // the clamp of k_hrtf_ols
+	}
+	__syncthreads();
+	uint16_t *myh = hist + (size_t)wave * dirs;
+	uint32_t rank[DIR_ROUNDS];
+	const uint64_t lt = (1ull << lane) - 1;
+#pragma unroll
+	for (int r = 0; r < DIR_ROUNDS; r++) {
+		uint64_t same = __ballot(valid[r]);
+#pragma unroll
+		for (int b = 0; b < DIR_KEY_BITS; b++) {
+			const bool bit = (key[r] >> b) & 1;
+			const uint64_t bb = __ballot(bit);
+			same &= bit ? bb : ~bb;
+		}
+		const uint32_t before = (uint32_t)__popcll(same & lt);
+		const uint32_t count = (uint32_t)__popcll(same);
+		uint32_t prev = 0;
+		if (valid[r]) {
+			prev = myh[key[r]];
+		}
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+		if (valid[r] && before == count - 1) { // one lane per distinct key of this round
+			myh[key[r]] = (uint16_t)(prev + count);
+		}
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+		rank[r] = prev + before;
+	}
+	__syncthreads();
+	for (uint32_t k = threadIdx.x; k < dirs; k += DIR_WAVES * 64) {
+		uint32_t run = 0;
+#pragma unroll
+		for (int w = 0; w < DIR_WAVES; w++) {
+			const uint32_t cnt = hist[(size_t)w * dirs + k];
+			hist[(size_t)w * dirs + k] = (uint16_t)run;
+			run += cnt;
+		}
+		base[k] = run;
+	}
+	__syncthreads();
+	if (wave == 0) { // exclusive scan of the per-key totals, 64 keys per trip (DPP row shifts + row broadcasts)
+		uint32_t carry = 0;
+		for (uint32_t k0 = 0; k0 < dirs; k0 += 64) {
+			const uint32_t k = k0 + lane;
+			const uint32_t v = k < dirs ? base[k] : 0;
+			int inc = (int)v;
+#define GAS_DPP_ADD(ctrl, rows) inc += __builtin_amdgcn_update_dpp(0, inc, ctrl, rows, 0xF, false)
+			GAS_DPP_ADD(0x111, 0xF); // row_shr:1
+			GAS_DPP_ADD(0x112, 0xF); // row_shr:2
+			GAS_DPP_ADD(0x114, 0xF); // row_shr:4
+			GAS_DPP_ADD(0x118, 0xF); // row_shr:8
+			GAS_DPP_ADD(0x142, 0xA); // row_bcast:15 -> rows 1, 3
+			GAS_DPP_ADD(0x143, 0xC); // row_bcast:31 -> rows 2, 3
+#undef GAS_DPP_ADD
+			if (k < dirs) {
+				base[k] = carry + (uint32_t)inc - v;
+			}
+			carry += (uint32_t)__builtin_amdgcn_readlane(inc, 63);
+		}
+	}
+	__syncthreads();
+#pragma unroll
+	for (int r = 0; r < DIR_ROUNDS; r++) {
+		if (valid[r]) {
+			const uint32_t e = seg0 + wave * (DIR_ROUNDS * 64) + r * 64 + lane;
+			const uint32_t dest = base[key[r]] + hist[(size_t)wave * dirs + key[r]] + rank[r];
+			order[seg0 + dest] = e;
+		}
+	}
+}
+
 } // namespace
 
 hipError_t gas_launch_noop(hipStream_t stream) {
 	hipLaunchKernelGGL(k_noop, dim3(1), dim3(64), 0, stream);
+	return hipGetLastError();
+}
+
+bool gas_dir_order_supported(uint32_t dirs) {
+	return dirs >= 1 && dirs <= (1u << DIR_KEY_BITS);
+}
+
+hipError_t gas_launch_dir_order(hipStream_t stream, const gas_group_args &g, const gas_params *params, const gas_params *fresh, uint32_t dirs, uint32_t *order) {
+	if (g.n == 0) {
+		return hipSuccess;
+	}
+	const uint32_t d2 = (dirs + 1) & ~1u; // keeps the u16 table's zeroing loop word-aligned
+	const size_t lds = (size_t)d2 * 4 + (size_t)DIR_WAVES * d2 * 2;
+	static bool raised = false; // > 64 KiB of dynamic LDS needs the opt-in, once per process
+	if (!raised) {
+		hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_dir_order), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+		if (e != hipSuccess) {
+			return e;
+		}
+		raised = true;
+	}
+	hipLaunchKernelGGL(k_dir_order, dim3((g.n + DIR_SEG - 1) / DIR_SEG), dim3(DIR_WAVES * 64), lds, stream, g, params, fresh, d2, order);
 	return hipGetLastError();
 }
 

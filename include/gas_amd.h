@@ -103,6 +103,12 @@ typedef struct gas_config {
  * block with both HRIRs and blend old -> new with t = i/F (the analogue of the per-block volume lerp,
  * audio_spatializer_3d.cpp:591-592) instead of switching at the block boundary. */
 #define GAS_FLAG_HRTF_CROSSFADE 2u
+/* Frequency-domain HRTF sources that follow each other in the callback's list with the SAME hrtf_dir are always
+ * summed before one forward FFT (a list kept grouped by direction costs ~15 % less).  With this flag the library
+ * also builds that grouping itself (a device counting sort per 8192-source segment, re-run after every parameter
+ * publish or list change).  Results are identical up to f32 summation order.  Pays only when parameters are
+ * published much less often than callbacks run (measured: DESIGN.md 3.1); no effect with GAS_FLAG_HRTF_CROSSFADE. */
+#define GAS_FLAG_DIRECTION_ORDER 4u
 
 /* SpatializerParameters (spatializer_parameters.h:39-67) + SpatializerParameters3D
  * (audio_spatializer_3d.h:61-83) as one 128-byte POD, plus the per-block effect

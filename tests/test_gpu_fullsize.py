@@ -80,6 +80,19 @@ def test_frequency_domain_mode_equals_exact_mode_at_full_size(gas):
     assert np.all(np.isposinf(pk))
 
 
+@pytest.mark.parametrize("case", ["cfg4_shard_hrtf_8192", "cfg5_erhrtf_4096"])
+def test_direction_order_leaves_the_mix_unchanged_at_full_size(gas, case):
+    """GAS_FLAG_DIRECTION_ORDER only regroups the frequency-domain sum (f32 summation order); it is also
+    bitwise reproducible run to run (the device sort is stable and atomic-free)."""
+    K = gas.capi
+    plain, _, _ = run(gas, case, flags=K.FLAG_PEAKS_DRAINING_ONLY)
+    ordered, pk, _ = run(gas, case, flags=K.FLAG_PEAKS_DRAINING_ONLY | K.FLAG_DIRECTION_ORDER)
+    again, _, _ = run(gas, case, flags=K.FLAG_PEAKS_DRAINING_ONLY | K.FLAG_DIRECTION_ORDER)
+    assert rel_rms(ordered, plain) <= TOL
+    assert np.array_equal(ordered, again)
+    assert np.all(np.isposinf(pk))
+
+
 @pytest.mark.parametrize("case", ["cfg3_hrtf_4096", "cfg5_erhrtf_4096"])
 def test_random_subset_against_oracle(gas, ob, case):
     """128 sources drawn from the full-size problem: GPU on the subset == oracle on the subset (and by the

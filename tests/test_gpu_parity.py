@@ -181,3 +181,36 @@ def test_biquad_extreme_filter_settings(gas, ob, cutoff, gain):
 
     run_pair(gas, ob, gas.capi.KIND_3D_MIX, (), 48, 512, 10, params_hook=hook)
     run_pair(gas, ob, gas.capi.KIND_EFFECT, (gas.capi.FX_HIGHSHELF,), 40, 512, 6, params_hook=hook)
+
+
+@pytest.mark.parametrize("n,dirs,chain,frames,ring", [(1100, 32, (3,), 512, 0), (9000, 64, (3,), 256, 0), (700, 16, (2, 3), 256, 4096)])
+def test_hrtf_direction_ordered_groups(gas, ob, n, dirs, chain, frames, ring):
+    """Frequency-domain groups large enough to be direction-ordered (k_dir_order): sources sharing an HRIR
+    direction are summed before ONE forward FFT.  Callbacks alternate between fresh parameters (order rebuilt),
+    unchanged parameters (order reused) and a changed slot list; draining sources keep the exact-peak path."""
+    from godot_audio_spatializer_amd import synth
+
+    rng = np.random.default_rng(n)
+    hrir = synth.synthetic_hrir(np.random.default_rng(7), dirs=dirs)
+    ctx = gas.SpatializerContext(max_sources=n, frames=frames, er_ring_frames=ring, flags=gas.capi.FLAG_PEAKS_DRAINING_ONLY | gas.capi.FLAG_DIRECTION_ORDER)
+    ctx.hrtf_load(hrir)
+    slots = ctx.source_alloc_many(n, gas.capi.KIND_EFFECT, chain)
+    draining = np.zeros(n, bool)
+    draining[5::37] = True
+    for s in slots[draining]:
+        ctx.source_set_draining(s, True)
+    ora = ob.BatchOracle(ob.KIND_EFFECT, n, frames, chain=chain, hrir=hrir, er_ring_frames=max(ring, 1))
+    perm = np.arange(n)
+    for b in range(5):
+        if b in (0, 1, 3):
+            p = synth.draw_params(rng, n, dirs=dirs, ring_frames=max(ring, 2 * frames), frames=frames)
+            ctx.params_publish_batch(slots, p)
+        if b == 4:
+            perm = rng.permutation(n)  # same playbacks, another callback order
+        src = synth.draw_sources(rng, n, frames)
+        mix, peaks = ctx.process_block(src[perm], slots[perm])
+        _, rpeaks, r64 = ora.block(p.astype(ob.PARAMS_DTYPE), src, want64=True)
+        assert rel_rms(mix[0], r64[0]) <= TOL, f"block {b}"
+        np.testing.assert_allclose(peaks[draining[perm]], rpeaks[perm][draining[perm]], rtol=2e-5, atol=1e-7)
+        assert np.all(np.isposinf(peaks[~draining[perm]]))
+    ctx.close()
