@@ -129,6 +129,7 @@ def main():
     ap.add_argument("--profile-every", type=int, default=4, help="bracket the dominant kernel of every Nth step with HIP events (markers cost ~2 us each)")
     ap.add_argument("--reduce-bucket", type=int, default=8, help="callbacks per cross-GPU reduce (N > 1)")
     ap.add_argument("--crossfade", action="store_true", help="GAS_FLAG_HRTF_CROSSFADE: blend old/new HRIRs when a source's direction changes (SURVEY 8f#4)")
+    ap.add_argument("--no-pipelined-mix", action="store_true", help="without GAS_FLAG_PIPELINED_MIX: the partial-mix sum of callback t runs before callback t+1's DSP kernel instead of under it")
     ap.add_argument("--direction-order", action="store_true", help="GAS_FLAG_DIRECTION_ORDER: let the library group sources by HRIR direction (device sort per publish)")
     ap.add_argument("--presorted-directions", action="store_true", help="diagnostic: publish parameters whose HRIR directions are already grouped in callback order")
     ap.add_argument("--exact-peaks", action="store_true", help="per-source inverse FFTs for every source (exact peak of every source)")
@@ -175,6 +176,8 @@ def main():
         flags |= gas.capi.FLAG_HRTF_CROSSFADE
     if args.direction_order:
         flags |= gas.capi.FLAG_DIRECTION_ORDER
+    if not args.no_pipelined_mix:
+        flags |= gas.capi.FLAG_PIPELINED_MIX  # callbacks are queued back to back here: overlap the tiny reduce with the next DSP kernel
     ctx = gas.SpatializerContext(max_sources=n_local, frames=frames, channel_count=1, er_ring_frames=ring, device=local_rank, flags=flags)
     stream = torch.cuda.current_stream()
     ctx.set_stream(stream.cuda_stream)
@@ -220,24 +223,34 @@ def main():
         raise SystemExit(f"gas_process_block failed: {rc}")
     torch.cuda.synchronize()
 
+    # raw device addresses, looked up once: tensor indexing costs microseconds per call and this loop is the host side
+    # of a ~20 us callback
+    pset_ptr = [t.data_ptr() for t in psets]
+    src_ptr = [t.data_ptr() for t in srcs]
+    out_ptr = [[buckets[b][i].data_ptr() for i in range(B)] for b in range(2)]
+    peaks_ptr = peaks.data_ptr()
+
     def step(k):
         if k % 2 == 0:
-            ctx.params_publish_device(psets[(k // 2) % 2].data_ptr(), n_local)
+            ctx.params_publish_device(pset_ptr[(k // 2) % 2], n_local)
         b, i = (k // B) % 2, k % B
         if i == 0:
             reducer.wait(pending[b])  # the bucket's previous reduce must be done before it is rewritten
             pending[b] = None
-        rc = ctx.process_block_raw(srcs[k % n_bufs].data_ptr(), None, n_local, frames, buckets[b][i].data_ptr(), peaks.data_ptr(), gas.capi.MEM_DEVICE)
+        rc = ctx.process_block_raw(src_ptr[k % n_bufs], None, n_local, frames, out_ptr[b][i], peaks_ptr, gas.capi.MEM_DEVICE)
         if rc != 0:
             raise SystemExit(f"gas_process_block failed: {rc}")
         if i == B - 1:
+            ctx.join_outputs()  # the bucket's B mixes, written on the library's reduce stream, before it is consumed
             pending[b] = reducer.reduce(buckets[b])
 
     def drain(k_end):
         if k_end % B != 0:  # a partly filled bucket still has to reach rank 0
             b = (k_end // B) % 2
             reducer.wait(pending[b])
+            ctx.join_outputs()
             pending[b] = reducer.reduce(buckets[b])
+        ctx.join_outputs()
         for i in range(2):
             reducer.wait(pending[i])
             pending[i] = None
@@ -254,6 +267,7 @@ def main():
     t0 = time.perf_counter()
     for k in range(args.steps):
         step(k)
+    t_enq = time.perf_counter() - t0
     drain(args.steps)
     torch.cuda.synchronize()
     if world > 1:
@@ -295,6 +309,8 @@ def main():
                 "sample_rate_hz": 48000,
                 "hrir_directions": args.dirs if hrir is not None else 0,
                 "hrir_crossfade": bool(args.crossfade),
+                "pipelined_mix": not args.no_pipelined_mix,
+                "host_enqueue_us_per_step": t_enq / args.steps * 1e6,
                 "peaks": "every source" if args.exact_peaks else f"draining sources only ({n_draining} of {n_local} per GPU)",
                 "parallelism": f"source-sharded x{world}, RCCL sum-reduce to rank 0 of {B} callbacks' partial mixes ({B * frames * 8} B) per collective, pipelined on a side stream" if world > 1 else "single GPU",
                 "realtime_budget_ms": frames / 48000.0 * 1e3,

@@ -25,6 +25,7 @@ MEM_DEVICE = 1
 FLAG_PEAKS_DRAINING_ONLY = 1
 FLAG_HRTF_CROSSFADE = 2
 FLAG_DIRECTION_ORDER = 4
+FLAG_PIPELINED_MIX = 8
 
 STATUS = {
     0: "GAS_OK",
@@ -131,6 +132,7 @@ EXPORTS = [
     "gas_ctx_destroy",
     "gas_ctx_set_stream",
     "gas_ctx_synchronize",
+    "gas_ctx_join_outputs",
     "gas_ctx_get_config",
     "gas_strerror",
     "gas_last_device_error",
@@ -195,6 +197,7 @@ def load_library():
     L.gas_ctx_destroy.restype = None
     L.gas_ctx_set_stream.argtypes = [vp, vp]
     L.gas_ctx_synchronize.argtypes = [vp]
+    L.gas_ctx_join_outputs.argtypes = [vp]
     L.gas_ctx_get_config.argtypes = [vp, C.POINTER(Config)]
     L.gas_strerror.argtypes = [i32]
     L.gas_strerror.restype = C.c_char_p
@@ -385,6 +388,10 @@ class SpatializerContext:
 
     def synchronize(self):
         self._check(self.lib.gas_ctx_synchronize(self.h), "gas_ctx_synchronize")
+
+    def join_outputs(self):
+        """FLAG_PIPELINED_MIX: order the context's stream behind every `out` written so far (non-blocking)."""
+        self._check(self.lib.gas_ctx_join_outputs(self.h), "gas_ctx_join_outputs")
 
     def profile_enable(self, on=1):
         self._check(self.lib.gas_profile_enable(self.h, int(on)), "gas_profile_enable")

@@ -65,6 +65,16 @@ struct gas_ctx {
 	gas_config cfg{};
 	hipStream_t stream = nullptr;
 	bool own_stream = false;
+	// GAS_FLAG_PIPELINED_MIX: the sum of callback t's partial mixes is carried out inside callback t+1's k_hrtf_ols
+	// launch (or by gas_ctx_join_outputs / the next ordered call); two generations of partials alternate
+	bool pipelined_mix = false;
+	uint32_t pipe_tick = 0;
+	struct PendingMix {
+		bool valid = false;
+		int parity = 0;
+		uint32_t p_total = 0;
+		gas_audio_frame *out = nullptr;
+	} pending_mix;
 	uint32_t hist_len = 0;
 	gas_dev_state st{};
 	gas_hrtf_table tab{};
@@ -294,14 +304,27 @@ int ensure_partials(gas_ctx *c, uint32_t rows) {
 		c->d_partials = nullptr;
 		c->partial_rows = 0;
 	}
-	const size_t bytes = (size_t)rows * c->cfg.channel_count * c->cfg.frames * 2 * sizeof(float);
+	// two generations when the reduce is pipelined: callback t+1 fills one while callback t's is being summed
+	const size_t bytes = (size_t)(c->pipelined_mix ? 2 : 1) * rows * c->cfg.channel_count * c->cfg.frames * 2 * sizeof(float);
 	GAS_HIP(c, hipMalloc(&c->d_partials, bytes));
 	c->partial_rows = rows;
 	return GAS_OK;
 }
 
+// Launches the pending callback's k_mix_reduce on the context's stream (GAS_FLAG_PIPELINED_MIX).
+int join_outputs(gas_ctx *c) {
+	if (c->pending_mix.valid) {
+		const gas_ctx::PendingMix pm = c->pending_mix;
+		c->pending_mix.valid = false;
+		const uint32_t F = c->cfg.frames;
+		const float *parts = c->d_partials + (size_t)pm.parity * c->partial_rows * c->cfg.channel_count * F * 2;
+		GAS_HIP(c, gas_launch_mix_reduce(c->stream, parts, pm.p_total, c->partial_rows, 1, F, pm.out));
+	}
+	return GAS_OK;
+}
+
 // Device work of one callback over already-grouped entries.
-int run_groups(gas_ctx *c, const gas_audio_frame *d_src, const uint32_t *d_slots, const uint32_t *d_rows, const Group *groups, const std::vector<ChainRange> &ranges, uint32_t n_total, gas_audio_frame *d_out, float *d_peaks, uint32_t channel_begin, uint32_t channel_count, int force_mode, bool use_order = false) {
+int run_groups(gas_ctx *c, const gas_audio_frame *d_src, const uint32_t *d_slots, const uint32_t *d_rows, const Group *groups, const std::vector<ChainRange> &ranges, uint32_t n_total, gas_audio_frame *d_out, float *d_peaks, uint32_t channel_begin, uint32_t channel_count, int force_mode, bool use_order = false, bool pipelined = false) {
 	const uint32_t F = c->cfg.frames;
 	uint32_t pcount[G_COUNT];
 	plan_partials(groups, ranges, pcount);
@@ -312,9 +335,36 @@ int run_groups(gas_ctx *c, const gas_audio_frame *d_src, const uint32_t *d_slots
 			p_mix = p_total;
 		}
 	}
-	int rc = ensure_partials(c, p_total > 0 ? p_total : 1);
+	// GAS_FLAG_PIPELINED_MIX: only callbacks that are one channel pair wide and carry an HRTF launch defer their sum
+	// A launch can carry the pending sum when it is the plain [HRTF] kernel (register budget), covers every output
+	// column with a workgroup and the pending callback left at most 256 partial rows (k_hrtf_ols: job_issue).
+	bool carrier = false;
+	if (groups[G_FX_HRTF].count + groups[G_FX_HRTF_PK].count > 0 && !c->fused_streams && (c->cfg.flags & GAS_FLAG_HRTF_CROSSFADE) == 0) {
+		gas_hrtf_launch_plan plan;
+		gas_hrtf_plan(groups[G_FX_HRTF].count, groups[G_FX_HRTF_PK].count, &plan);
+		carrier = (plan.wgs_fd + plan.wgs_pk) * GAS_HRTF_JOB_WAVES >= F * 2 / 4 && c->pending_mix.p_total <= 256;
+	}
+	pipelined = pipelined && c->pipelined_mix && channel_count == 1 && c->cfg.channel_count == 1;
+	int rc = GAS_OK;
+	if (!pipelined || !carrier || (p_total > 0 ? p_total : 1) > c->partial_rows) {
+		rc = join_outputs(c); // nobody to carry the pending sum (or the partials are about to move): do it now
+		if (rc != GAS_OK) {
+			return rc;
+		}
+	}
+	rc = ensure_partials(c, p_total > 0 ? p_total : 1);
 	if (rc != GAS_OK) {
 		return rc;
+	}
+	const int parity = pipelined ? (int)(c->pipe_tick & 1) : 0;
+	float *const parts = c->d_partials + (size_t)parity * c->partial_rows * c->cfg.channel_count * F * 2;
+	gas_deferred_reduce job; // handed to the first HRTF launch of this callback
+	if (c->pending_mix.valid) {
+		job.partials = c->d_partials + (size_t)c->pending_mix.parity * c->partial_rows * c->cfg.channel_count * F * 2;
+		job.p_count = c->pending_mix.p_total;
+		job.elems = F * 2;
+		job.out = reinterpret_cast<float *>(c->pending_mix.out);
+		c->pending_mix.valid = false;
 	}
 	// only k_biquad_mix accumulates peaks (atomicMax over channel pairs); the other kernels store them
 	bool biquad_groups = false;
@@ -363,13 +413,13 @@ int run_groups(gas_ctx *c, const gas_audio_frame *d_src, const uint32_t *d_slots
 				}
 				const uint32_t cb = mode == GAS_MODE_MIX_CHANNEL ? channel_begin : 0;
 				const uint32_t cc = mode == GAS_MODE_MIX_CHANNEL ? channel_count : 1;
-				e = gas_launch_biquad_mix(c->stream, mode, ga, c->st, F, cb, cc, c->cfg.mix_rate, c->d_partials, p_off, c->partial_rows);
+				e = gas_launch_biquad_mix(c->stream, mode, ga, c->st, F, cb, cc, c->cfg.mix_rate, parts, p_off, c->partial_rows);
 			} break;
 			case G_FX_COPY:
-				e = gas_launch_biquad_mix(c->stream, GAS_MODE_COPY, ga, c->st, F, 0, 1, c->cfg.mix_rate, c->d_partials, p_off, c->partial_rows);
+				e = gas_launch_biquad_mix(c->stream, GAS_MODE_COPY, ga, c->st, F, 0, 1, c->cfg.mix_rate, parts, p_off, c->partial_rows);
 				break;
 			case G_FX_SHELF:
-				e = gas_launch_biquad_mix(c->stream, GAS_MODE_FX_HIGHSHELF, ga, c->st, F, 0, 1, c->cfg.mix_rate, c->d_partials, p_off, c->partial_rows);
+				e = gas_launch_biquad_mix(c->stream, GAS_MODE_FX_HIGHSHELF, ga, c->st, F, 0, 1, c->cfg.mix_rate, parts, p_off, c->partial_rows);
 				break;
 			case G_FX_HRTF_PK:
 			case G_FX_ER_HRTF_PK:
@@ -416,7 +466,10 @@ int run_groups(gas_ctx *c, const gas_audio_frame *d_src, const uint32_t *d_slots
 						g_fd.order = ord;
 					}
 				}
-				e = gas_launch_hrtf_ols(c->stream, fd_gt == G_FX_ER_HRTF, (c->cfg.flags & GAS_FLAG_HRTF_CROSSFADE) != 0, g_fd, g_pk, c->st, c->tab, c->d_tw, F, c->hist_len, c->cfg.er_ring_frames, c->d_partials, p_off, fd_gt == G_FX_HRTF && c->fused_streams ? c->d_cursors : nullptr, c->d_fade_env, fresh);
+				e = gas_launch_hrtf_ols(c->stream, fd_gt == G_FX_ER_HRTF, (c->cfg.flags & GAS_FLAG_HRTF_CROSSFADE) != 0, g_fd, g_pk, c->st, c->tab, c->d_tw, F, c->hist_len, c->cfg.er_ring_frames, parts, p_off, fd_gt == G_FX_HRTF && c->fused_streams ? c->d_cursors : nullptr, c->d_fade_env, fresh, fd_gt == G_FX_HRTF ? job : gas_deferred_reduce());
+				if (fd_gt == G_FX_HRTF) {
+					job = gas_deferred_reduce();
+				}
 			} break;
 			case G_FX_GENERIC: {
 				// audio_spatializer_effect.cpp:52-76 on the device: effect j reads the previous stage's rows and writes
@@ -452,9 +505,9 @@ int run_groups(gas_ctx *c, const gas_audio_frame *d_src, const uint32_t *d_slots
 						}
 						gas_audio_frame *outb = c->d_chain[j & 1];
 						if (kind == GAS_FX_HIGHSHELF) {
-							e = gas_launch_biquad_mix(c->stream, GAS_MODE_FX_HIGHSHELF, in, c->st, F, (uint32_t)j, 1, c->cfg.mix_rate, c->d_partials, 0, c->partial_rows, reinterpret_cast<float *>(outb));
+							e = gas_launch_biquad_mix(c->stream, GAS_MODE_FX_HIGHSHELF, in, c->st, F, (uint32_t)j, 1, c->cfg.mix_rate, parts, 0, c->partial_rows, reinterpret_cast<float *>(outb));
 						} else if (kind == GAS_FX_EARLY_REFLECTIONS) {
-							e = gas_launch_er_only(c->stream, in, c->st, F, c->cfg.er_ring_frames, c->d_partials, 0, c->partial_rows, outb);
+							e = gas_launch_er_only(c->stream, in, c->st, F, c->cfg.er_ring_frames, parts, 0, c->partial_rows, outb);
 						} else {
 							e = gas_launch_hrtf_rows(c->stream, (c->cfg.flags & GAS_FLAG_HRTF_CROSSFADE) != 0, in, c->st, c->tab, c->d_tw, F, outb);
 						}
@@ -464,13 +517,13 @@ int run_groups(gas_ctx *c, const gas_audio_frame *d_src, const uint32_t *d_slots
 					if (e == hipSuccess) {
 						gas_group_args fin = in;
 						fin.rows = peak_rows; // peaks go to the callback's row of each source
-						e = gas_launch_rows_accumulate(c->stream, fin, F, c->d_partials, pp);
+						e = gas_launch_rows_accumulate(c->stream, fin, F, parts, pp);
 					}
 					pp += gas_hrtf_partials(r.count, nullptr);
 				}
 			} break;
 			case G_FX_ER:
-				e = gas_launch_er_only(c->stream, ga, c->st, F, c->cfg.er_ring_frames, c->d_partials, p_off, c->partial_rows);
+				e = gas_launch_er_only(c->stream, ga, c->st, F, c->cfg.er_ring_frames, parts, p_off, c->partial_rows);
 				break;
 		}
 		GAS_HIP(c, e);
@@ -488,9 +541,20 @@ int run_groups(gas_ctx *c, const gas_audio_frame *d_src, const uint32_t *d_slots
 	}
 
 	// channel pair 0 sums every group's partials; pairs > 0 only the mix_channel group's (which come first)
-	GAS_HIP(c, gas_launch_mix_reduce(c->stream, c->d_partials, p_total, c->partial_rows, 1, F, d_out));
+	if (job.partials) { // no launch took the pending sum along (cannot happen with hrtf_launch set; kept for safety)
+		GAS_HIP(c, gas_launch_mix_reduce(c->stream, job.partials, job.p_count, c->partial_rows, 1, F, reinterpret_cast<gas_audio_frame *>(job.out)));
+	}
+	if (pipelined) { // summed by the next callback's HRTF launch, gas_ctx_join_outputs or the next ordered call
+		c->pending_mix.valid = true;
+		c->pending_mix.parity = parity;
+		c->pending_mix.p_total = p_total;
+		c->pending_mix.out = d_out;
+		c->pipe_tick++;
+		return GAS_OK;
+	}
+	GAS_HIP(c, gas_launch_mix_reduce(c->stream, parts, p_total, c->partial_rows, 1, F, d_out));
 	if (channel_count > 1) {
-		GAS_HIP(c, gas_launch_mix_reduce(c->stream, c->d_partials + (size_t)c->partial_rows * F * 2, p_mix, c->partial_rows, channel_count - 1, F, d_out + F));
+		GAS_HIP(c, gas_launch_mix_reduce(c->stream, parts + (size_t)c->partial_rows * F * 2, p_mix, c->partial_rows, channel_count - 1, F, d_out + F));
 	}
 	return GAS_OK;
 }
@@ -778,6 +842,7 @@ int gas_ctx_create(const gas_config *cfg, gas_ctx **out_ctx) {
 		GAS_HIP(c, hipSetDevice(cfg->device));
 		GAS_HIP(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
 		c->own_stream = true;
+		c->pipelined_mix = (cfg->flags & GAS_FLAG_PIPELINED_MIX) != 0;
 		c->st.bq_stride = N * 8;
 		GAS_HIP(c, hipMalloc(&c->st.bq, sizeof(float) * GAS_BQ_FIELDS * c->st.bq_stride));
 		GAS_HIP(c, hipMemsetAsync(c->st.bq, 0, sizeof(float) * GAS_BQ_FIELDS * c->st.bq_stride, c->stream));
@@ -856,6 +921,12 @@ int gas_ctx_set_stream(gas_ctx *c, void *hip_stream) {
 		return GAS_ERR_INVALID_ARGUMENT;
 	}
 	GAS_HIP(c, hipSetDevice(c->cfg.device));
+	{
+		int rcj = join_outputs(c);
+		if (rcj != GAS_OK) {
+			return rcj;
+		}
+	}
 	GAS_HIP(c, hipStreamSynchronize(c->stream));
 	if (c->own_stream) {
 		GAS_HIP(c, hipStreamDestroy(c->stream));
@@ -877,8 +948,23 @@ int gas_ctx_synchronize(gas_ctx *c) {
 	if (!c) {
 		return GAS_ERR_INVALID_ARGUMENT;
 	}
+	GAS_HIP(c, hipSetDevice(c->cfg.device));
+	{
+		int rcj = join_outputs(c);
+		if (rcj != GAS_OK) {
+			return rcj;
+		}
+	}
 	GAS_HIP(c, hipStreamSynchronize(c->stream));
 	return GAS_OK;
+}
+
+int gas_ctx_join_outputs(gas_ctx *c) {
+	if (!c) {
+		return GAS_ERR_INVALID_ARGUMENT;
+	}
+	GAS_HIP(c, hipSetDevice(c->cfg.device));
+	return join_outputs(c);
 }
 
 int gas_source_alloc(gas_ctx *c, int kind, const int32_t *effects, uint32_t n_effects, uint32_t *out_slot) {
@@ -1309,6 +1395,9 @@ int gas_process_block_streams(gas_ctx *c, const uint32_t *slots, uint32_t n, uin
 	int rc = gas_process_block(c, rows, list, n, F, c->d_out, c->d_peaks, GAS_MEM_DEVICE);
 	c->fused_streams = false;
 	c->stream_groups_gen = rc == GAS_OK ? c->groups_gen : UINT64_MAX;
+	if (rc == GAS_OK) {
+		rc = join_outputs(c);
+	}
 	if (rc != GAS_OK) {
 		return fail(rc);
 	}
@@ -1446,7 +1535,7 @@ int gas_process_block(gas_ctx *c, const gas_audio_frame *src, const uint32_t *sl
 			}
 		}
 	}
-	rc = run_groups(c, d_src, c->d_slots, c->cached_identity_rows ? nullptr : c->d_rows, c->groups, c->chain_ranges, n, d_out, d_peaks, 0, C, -1, true);
+	rc = run_groups(c, d_src, c->d_slots, c->cached_identity_rows ? nullptr : c->d_rows, c->groups, c->chain_ranges, n, d_out, d_peaks, 0, C, -1, true, mem == GAS_MEM_DEVICE);
 	c->fresh_for_launch = nullptr;
 	if (rc != GAS_OK) {
 		return fail(rc);

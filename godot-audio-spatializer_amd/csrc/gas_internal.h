@@ -55,6 +55,16 @@ struct gas_group_args {
 	const uint32_t *order = nullptr; // [n] k_hrtf_ols only: processing order (entries grouped by HRIR direction), or nullptr = entry order
 };
 
+// GAS_FLAG_PIPELINED_MIX: the final sum of the PREVIOUS callback's partial mixes (exactly k_mix_reduce's job for one
+// channel pair), carried out by otherwise idle waves of this callback's k_hrtf_ols launch.  partials == nullptr: none.
+#define GAS_HRTF_JOB_WAVES 6 // waves of a k_hrtf_ols workgroup that can each sum one output column of the previous callback
+struct gas_deferred_reduce {
+	const float *partials = nullptr; // [p_count][elems]
+	uint32_t p_count = 0;
+	uint32_t elems = 0; // F * 2
+	float *out = nullptr;
+};
+
 enum gas_biquad_mode {
 	GAS_MODE_MIX_CHANNEL = 0, // audio_spatializer_3d.cpp:554-609
 	GAS_MODE_PROCESS_FRAMES = 1, // audio_spatializer_3d.cpp:491-552
@@ -79,7 +89,7 @@ struct gas_hrtf_launch_plan {
 };
 void gas_hrtf_plan(uint32_t n_fd, uint32_t n_pk, gas_hrtf_launch_plan *plan);
 uint32_t gas_hrtf_partials(uint32_t n, uint32_t *sources_per_wave); // plan for a single-path launch (k_er_only)
-hipError_t gas_launch_hrtf_ols(hipStream_t stream, bool with_er, bool crossfade, const gas_group_args &g_fd, const gas_group_args &g_pk, const gas_dev_state &st, const gas_hrtf_table &tab, const float2 *twiddles, uint32_t frames, uint32_t hist_len, uint32_t er_ring_frames, float *partials, uint32_t p_offset, gas_cursor *cursors /* non-null: sample the bound streams in the kernel */, const float *fade_env, const gas_params *fresh /* non-null: unscattered parameter rows in row order */);
+hipError_t gas_launch_hrtf_ols(hipStream_t stream, bool with_er, bool crossfade, const gas_group_args &g_fd, const gas_group_args &g_pk, const gas_dev_state &st, const gas_hrtf_table &tab, const float2 *twiddles, uint32_t frames, uint32_t hist_len, uint32_t er_ring_frames, float *partials, uint32_t p_offset, gas_cursor *cursors /* non-null: sample the bound streams in the kernel */, const float *fade_env, const gas_params *fresh /* non-null: unscattered parameter rows in row order */, const gas_deferred_reduce &job = gas_deferred_reduce());
 hipError_t gas_launch_er_only(hipStream_t stream, const gas_group_args &g, const gas_dev_state &st, uint32_t frames, uint32_t er_ring_frames, float *partials, uint32_t p_offset, uint32_t p_stride, gas_audio_frame *rows_out = nullptr);
 // stages of a general effect chain (rows in -> rows out) and its final mix
 hipError_t gas_launch_hrtf_rows(hipStream_t stream, bool crossfade, const gas_group_args &g, const gas_dev_state &st, const gas_hrtf_table &tab, const float2 *twiddles, uint32_t frames, gas_audio_frame *rows_out);

@@ -164,6 +164,9 @@ int gas_multi_process_block(gas_multi *m, const gas_audio_frame *const *src, con
 			}
 		}
 		rc = gas_process_block(m->shard[g], staged[g], slots[g], n[g], F, m->d_out[g], m->d_peaks[g], GAS_MEM_DEVICE);
+		if (rc == GAS_OK) {
+			rc = gas_ctx_join_outputs(m->shard[g]); // the gather below runs on the shard's stream
+		}
 		if (rc != GAS_OK) {
 			break;
 		}

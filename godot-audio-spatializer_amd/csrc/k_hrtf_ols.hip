@@ -383,6 +383,43 @@ __device__ __forceinline__ void finish_spectra(int lane, float4 (&hs)[8]) {
 	}
 }
 
+// The previous callback's k_mix_reduce, done by one wave of this workgroup for float4 column `col` (one column per
+// job wave; the context only hands a job over when the grid covers every column and p_count <= 256).  The four
+// partial rows a lane sums are loaded at kernel start and parked in registers, so the sum itself -- the same
+// operations in the same order as k_mix_reduce with lane = its `prow`, hence the same bits -- finds them landed
+// and hides behind the other waves' epilogue.
+constexpr int JOB_ROWS = 4; // rows lane, lane + 64, lane + 128, lane + 192
+__device__ __forceinline__ void job_issue(const gas_deferred_reduce &j, uint32_t col, int lane, float4 (&jr)[JOB_ROWS]) {
+	const uint32_t e4 = j.elems / 4;
+	const float4 *p = reinterpret_cast<const float4 *>(j.partials) + col;
+#pragma unroll
+	for (int r = 0; r < JOB_ROWS; r++) {
+		const uint32_t k = (uint32_t)lane + 64u * r;
+		const float4 v = p[(size_t)(k < j.p_count ? k : 0) * e4];
+		const float keep = k < j.p_count ? 1.0f : 0.0f; // missing rows contribute +0: x + 0 = x changes no bit
+		jr[r] = make_float4(keep != 0.0f ? v.x : 0.0f, keep != 0.0f ? v.y : 0.0f, keep != 0.0f ? v.z : 0.0f, keep != 0.0f ? v.w : 0.0f);
+	}
+}
+
+__device__ __forceinline__ void job_finish(const gas_deferred_reduce &j, uint32_t col, int lane, const float4 (&jr)[JOB_ROWS], float4 *red) {
+	float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+	for (int r = 0; r < JOB_ROWS; r++) {
+		s.x += jr[r].x; s.y += jr[r].y; s.z += jr[r].z; s.w += jr[r].w;
+	}
+	red[lane] = s;
+	wave_lds_sync();
+	if (lane == 0) {
+		float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 8
+		for (int q = 0; q < 64; q++) {
+			const float4 a = red[q];
+			t.x += a.x; t.y += a.y; t.z += a.z; t.w += a.w;
+		}
+		reinterpret_cast<float4 *>(j.out)[col] = t;
+	}
+}
+
 // SQ = S/64 = F/128: 4 for F = 512, 2 for F = 256.
 //
 // PEAKS = true : every source gets its own pair of inverse FFTs, so its output peak (the input of the
@@ -405,7 +442,7 @@ struct HrtfLds {
 };
 
 template <int SQ, bool WITH_ER, bool PEAKS, bool SRC_PCM, bool XFADE>
-__device__ __forceinline__ void hrtf_body(float2 *lds_all, const uint32_t wg, const gas_group_args &g, const gas_dev_state &st, const gas_hrtf_table &tab, const float2 *__restrict__ tw, uint32_t spw, uint32_t er_R, float *__restrict__ my_partial, gas_cursor *__restrict__ cursors, const float *__restrict__ fade_env, const gas_params *__restrict__ fresh, gas_audio_frame *__restrict__ rows_out = nullptr) {
+__device__ __forceinline__ void hrtf_body(float2 *lds_all, const uint32_t wg, const gas_group_args &g, const gas_dev_state &st, const gas_hrtf_table &tab, const float2 *__restrict__ tw, uint32_t spw, uint32_t er_R, float *__restrict__ my_partial, gas_cursor *__restrict__ cursors, const float *__restrict__ fade_env, const gas_params *__restrict__ fresh, gas_audio_frame *__restrict__ rows_out = nullptr, const gas_deferred_reduce job = gas_deferred_reduce(), float4 *job_red = nullptr, uint32_t job_col = 0, uint32_t job_nwg = 1) {
 	static_assert(!(WITH_ER && SRC_PCM), "the early-reflection prologue reads float rows");
 	constexpr int FQ = 2 * SQ; // F / 64
 	constexpr int HQ = 8 - SQ; // hist_len / 64
@@ -424,6 +461,21 @@ __device__ __forceinline__ void hrtf_body(float2 *lds_all, const uint32_t wg, co
 	for (int k = 0; k < 8; k++) {
 		t1[k] = tw[lane * 16 + k];
 		t2[k] = tw[lane * 16 + 8 + k];
+	}
+
+	// GAS_FLAG_PIPELINED_MIX: one wave also sums the previous callback's partial mixes for one output column
+	// (waves 2 .. WAVES-1, idle while waves 0 and 1 run the frequency-domain epilogue's inverse FFTs, take columns
+	// wg, wg + n_wg, ...: GAS_HRTF_JOB_WAVES columns per workgroup at most)
+	constexpr bool JOB_OK = !WITH_ER && !SRC_PCM && !XFADE; // register budget: the plain chain only
+	float4 jr[JOB_ROWS];
+	bool job_mine = false;
+	if constexpr (JOB_OK) {
+		job_col = job_col + (uint32_t)(wave - 2) * job_nwg;
+		job_red += (wave >= 2 ? wave - 2 : 0) * 64;
+		job_mine = job.partials != nullptr && wave >= 2 && job_col < job.elems / 4; // wave-uniform
+		if (job_mine) {
+			job_issue(job, job_col, lane, jr);
+		}
 	}
 
 	// running sum of this wave's sources: time domain (PEAKS) or frequency domain
@@ -766,6 +818,11 @@ __device__ __forceinline__ void hrtf_body(float2 *lds_all, const uint32_t wg, co
 		for (int t = 0; t < FQ; t++) {
 			*reinterpret_cast<float2 *>(red + (lane + 64 * t) * 2) = make_float2(accL[t], accR[t]);
 		}
+		if constexpr (JOB_OK) {
+			if (job_mine) {
+				job_finish(job, job_col, lane, jr, job_red);
+			}
+		}
 		__syncthreads();
 		const float *red_all = reinterpret_cast<const float *>(lds_all);
 		for (int idx = threadIdx.x; idx < (int)(F * 2); idx += WAVES * 64) {
@@ -807,6 +864,11 @@ __device__ __forceinline__ void hrtf_body(float2 *lds_all, const uint32_t wg, co
 				}
 			}
 			__syncthreads();
+			if constexpr (JOB_OK) {
+				if (job_mine && round == 0) { // waves 2.. idle while 0 and 1 transform: the previous callback's sum
+					job_finish(job, job_col, lane, jr, job_red);
+				}
+			}
 			if (wave < 2) {
 				float2 y[8];
 #pragma unroll
@@ -845,19 +907,22 @@ __device__ __forceinline__ void hrtf_body(float2 *lds_all, const uint32_t wg, co
 	(void)bYL;
 	(void)bYR;
 	(void)zs;
+	(void)jr;
+	(void)job_mine;
 }
 
 // One launch per callback for every HRTF source: workgroups [0, wgs_fd) run the frequency-domain body over
 // g_fd, the rest run the exact-peak body over g_pk (the draining playbacks).
 template <int SQ, bool WITH_ER, bool SRC_PCM, bool XFADE>
-__global__ __launch_bounds__(WAVES * 64, GAS_HRTF_WAVES_PER_SIMD) void k_hrtf_ols(gas_group_args g_fd, gas_group_args g_pk, uint32_t wgs_fd, gas_dev_state st, gas_hrtf_table tab, const float2 *__restrict__ tw, uint32_t spw_fd, uint32_t spw_pk, uint32_t er_R, float *__restrict__ partials, uint32_t p_offset, gas_cursor *__restrict__ cursors, const float *__restrict__ fade_env, const gas_params *__restrict__ fresh) {
+__global__ __launch_bounds__(WAVES * 64, GAS_HRTF_WAVES_PER_SIMD) void k_hrtf_ols(gas_group_args g_fd, gas_group_args g_pk, uint32_t wgs_fd, gas_dev_state st, gas_hrtf_table tab, const float2 *__restrict__ tw, uint32_t spw_fd, uint32_t spw_pk, uint32_t er_R, float *__restrict__ partials, uint32_t p_offset, gas_cursor *__restrict__ cursors, const float *__restrict__ fade_env, const gas_params *__restrict__ fresh, gas_deferred_reduce job) {
 	constexpr int LDS_F2 = HrtfLds<SQ, false>::TOTAL_F2 > HrtfLds<SQ, true>::TOTAL_F2 ? HrtfLds<SQ, false>::TOTAL_F2 : HrtfLds<SQ, true>::TOTAL_F2;
 	__shared__ float2 lds_all[LDS_F2];
+	__shared__ float4 job_red[GAS_HRTF_JOB_WAVES * 64];
 	float *my_partial = partials + ((size_t)p_offset + blockIdx.x) * (size_t)(2 * SQ * 64 * 2);
 	if (blockIdx.x < wgs_fd) {
-		hrtf_body<SQ, WITH_ER, false, SRC_PCM, XFADE>(lds_all, blockIdx.x, g_fd, st, tab, tw, spw_fd, er_R, my_partial, cursors, fade_env, fresh);
+		hrtf_body<SQ, WITH_ER, false, SRC_PCM, XFADE>(lds_all, blockIdx.x, g_fd, st, tab, tw, spw_fd, er_R, my_partial, cursors, fade_env, fresh, nullptr, job, job_red, blockIdx.x, gridDim.x);
 	} else {
-		hrtf_body<SQ, WITH_ER, true, SRC_PCM, XFADE>(lds_all, blockIdx.x - wgs_fd, g_pk, st, tab, tw, spw_pk, er_R, my_partial, cursors, fade_env, fresh);
+		hrtf_body<SQ, WITH_ER, true, SRC_PCM, XFADE>(lds_all, blockIdx.x - wgs_fd, g_pk, st, tab, tw, spw_pk, er_R, my_partial, cursors, fade_env, fresh, nullptr, job, job_red, blockIdx.x, gridDim.x);
 	}
 }
 
@@ -1083,7 +1148,7 @@ uint32_t gas_hrtf_partials(uint32_t n, uint32_t *sources_per_wave) {
 	return p.wgs_fd;
 }
 
-hipError_t gas_launch_hrtf_ols(hipStream_t stream, bool with_er, bool crossfade, const gas_group_args &g_fd, const gas_group_args &g_pk, const gas_dev_state &st, const gas_hrtf_table &tab, const float2 *twiddles, uint32_t frames, uint32_t hist_len, uint32_t er_ring_frames, float *partials, uint32_t p_offset, gas_cursor *cursors, const float *fade_env, const gas_params *fresh) {
+hipError_t gas_launch_hrtf_ols(hipStream_t stream, bool with_er, bool crossfade, const gas_group_args &g_fd, const gas_group_args &g_pk, const gas_dev_state &st, const gas_hrtf_table &tab, const float2 *twiddles, uint32_t frames, uint32_t hist_len, uint32_t er_ring_frames, float *partials, uint32_t p_offset, gas_cursor *cursors, const float *fade_env, const gas_params *fresh, const gas_deferred_reduce &job) {
 	if (g_fd.n + g_pk.n == 0) {
 		return hipSuccess;
 	}
@@ -1095,7 +1160,7 @@ hipError_t gas_launch_hrtf_ols(hipStream_t stream, bool with_er, bool crossfade,
 	const uint32_t wgs_fd = plan.wgs_fd, spw_fd = plan.spw_fd, spw_pk = plan.spw_pk;
 	dim3 grid(plan.wgs_fd + plan.wgs_pk), block(WAVES * 64);
 #define GAS_HRTF_LAUNCH(SQv, ERv, PCMv, XFv) \
-	hipLaunchKernelGGL((k_hrtf_ols<SQv, ERv, PCMv, XFv>), grid, block, 0, stream, g_fd, g_pk, wgs_fd, st, tab, twiddles, spw_fd, spw_pk, er_ring_frames, partials, p_offset, cursors, fade_env, fresh)
+	hipLaunchKernelGGL((k_hrtf_ols<SQv, ERv, PCMv, XFv>), grid, block, 0, stream, g_fd, g_pk, wgs_fd, st, tab, twiddles, spw_fd, spw_pk, er_ring_frames, partials, p_offset, cursors, fade_env, fresh, job)
 #define GAS_HRTF_CASE3(SQv, XFv)                      \
 	if (with_er) {                                    \
 		GAS_HRTF_LAUNCH(SQv, true, false, XFv);       \

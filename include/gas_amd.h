@@ -109,6 +109,15 @@ typedef struct gas_config {
  * publish or list change).  Results are identical up to f32 summation order.  Pays only when parameters are
  * published much less often than callbacks run (measured: DESIGN.md 3.1); no effect with GAS_FLAG_HRTF_CROSSFADE. */
 #define GAS_FLAG_DIRECTION_ORDER 4u
+/* Throughput mode for callers that queue many callbacks (offline rendering, benchmarks): the final sum of the
+ * per-workgroup partial mixes of gas_process_block(GAS_MEM_DEVICE) is not launched as its own kernel; it is carried
+ * out by otherwise idle waves of the NEXT callback's HRTF kernel (one dispatch per callback instead of two).  `out`
+ * of such a call is complete only after the next gas_process_block on this context, gas_ctx_join_outputs(),
+ * gas_ctx_synchronize(), or any GAS_MEM_HOST / single-instance call -- each in the context's stream order; peaks
+ * are not deferred.  Keep `out` valid and unread until then.  Applies to contexts with channel_count == 1 whose
+ * callback contains HRTF sources; other callbacks are summed immediately.  Same operations in the same order:
+ * results are bitwise identical to the ordered mode.  A synchronous audio callback gains nothing from it. */
+#define GAS_FLAG_PIPELINED_MIX 8u
 
 /* SpatializerParameters (spatializer_parameters.h:39-67) + SpatializerParameters3D
  * (audio_spatializer_3d.h:61-83) as one 128-byte POD, plus the per-block effect
@@ -144,6 +153,9 @@ void gas_ctx_destroy(gas_ctx *ctx);
 /* Run on an existing HIP stream (hipStream_t) instead of the context's own. */
 int gas_ctx_set_stream(gas_ctx *ctx, void *hip_stream);
 int gas_ctx_synchronize(gas_ctx *ctx);
+/* GAS_FLAG_PIPELINED_MIX: enqueue the deferred sum of the last gas_process_block, so that work enqueued on the
+ * context's stream after this call sees its `out`.  Non-blocking; no-op when nothing is pending. */
+int gas_ctx_join_outputs(gas_ctx *ctx);
 int gas_ctx_get_config(gas_ctx *ctx, gas_config *out); /* the configuration the context was created with */
 const char *gas_strerror(int status);
 const char *gas_last_device_error(gas_ctx *ctx);

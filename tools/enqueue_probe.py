@@ -13,7 +13,7 @@ from godot_audio_spatializer_amd import synth  # noqa: E402
 
 def run(n, steps=400):
     rng = np.random.default_rng(0)
-    ctx = gas.SpatializerContext(max_sources=n, frames=512, flags=gas.capi.FLAG_PEAKS_DRAINING_ONLY)
+    ctx = gas.SpatializerContext(max_sources=n, frames=512, flags=gas.capi.FLAG_PEAKS_DRAINING_ONLY | (gas.capi.FLAG_PIPELINED_MIX if "pipe" in sys.argv else 0))
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
     ctx.hrtf_load(synth.synthetic_hrir(rng, dirs=1024))
     slots = ctx.source_alloc_many(n, 2, (3,))
