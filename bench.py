@@ -131,7 +131,7 @@ def main():
     ap.add_argument("--crossfade", action="store_true", help="GAS_FLAG_HRTF_CROSSFADE: blend old/new HRIRs when a source's direction changes (SURVEY 8f#4)")
     ap.add_argument("--no-pipelined-mix", action="store_true", help="without GAS_FLAG_PIPELINED_MIX: the partial-mix sum of callback t runs before callback t+1's DSP kernel instead of under it")
     ap.add_argument("--direction-order", action="store_true", help="GAS_FLAG_DIRECTION_ORDER: let the library group sources by HRIR direction (device sort per publish)")
-    ap.add_argument("--presorted-directions", action="store_true", help="diagnostic: publish parameters whose HRIR directions are already grouped in callback order")
+    ap.add_argument("--presorted-directions", action="store_true", help="GAS_FLAG_DIRECTION_RUNS with parameters whose HRIR directions are grouped in callback order (what a caller that sorts its list gets)")
     ap.add_argument("--exact-peaks", action="store_true", help="per-source inverse FFTs for every source (exact peak of every source)")
     args = ap.parse_args()
 
@@ -176,6 +176,8 @@ def main():
         flags |= gas.capi.FLAG_HRTF_CROSSFADE
     if args.direction_order:
         flags |= gas.capi.FLAG_DIRECTION_ORDER
+    if args.presorted_directions:
+        flags |= gas.capi.FLAG_DIRECTION_RUNS
     if not args.no_pipelined_mix:
         flags |= gas.capi.FLAG_PIPELINED_MIX  # callbacks are queued back to back here: overlap the tiny reduce with the next DSP kernel
     ctx = gas.SpatializerContext(max_sources=n_local, frames=frames, channel_count=1, er_ring_frames=ring, device=local_rank, flags=flags)

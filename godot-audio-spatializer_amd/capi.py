@@ -26,6 +26,7 @@ FLAG_PEAKS_DRAINING_ONLY = 1
 FLAG_HRTF_CROSSFADE = 2
 FLAG_DIRECTION_ORDER = 4
 FLAG_PIPELINED_MIX = 8
+FLAG_DIRECTION_RUNS = 16
 
 STATUS = {
     0: "GAS_OK",
@@ -167,7 +168,8 @@ _lib = None
 
 
 def library_path():
-    return _build.LIB
+    # GAS_AMD_LIB: development override for A/B-ing kernel builds (tools/README.md); never a fallback
+    return os.environ.get("GAS_AMD_LIB") or _build.LIB
 
 
 def load_library():

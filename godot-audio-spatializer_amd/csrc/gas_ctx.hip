@@ -404,6 +404,7 @@ int run_groups(gas_ctx *c, const gas_audio_frame *d_src, const uint32_t *d_slots
 			GAS_HIP(c, hipEventRecord(c->ev[c->ev_used], c->stream));
 		}
 		hipError_t e = hipSuccess;
+		uint64_t carried_bytes = 0; // the previous callback's partial mixes summed inside this launch (GAS_FLAG_PIPELINED_MIX)
 		switch (gt) {
 			case G_3D_MIX:
 			case G_3D_PROCESS: {
@@ -466,8 +467,9 @@ int run_groups(gas_ctx *c, const gas_audio_frame *d_src, const uint32_t *d_slots
 						g_fd.order = ord;
 					}
 				}
-				e = gas_launch_hrtf_ols(c->stream, fd_gt == G_FX_ER_HRTF, (c->cfg.flags & GAS_FLAG_HRTF_CROSSFADE) != 0, g_fd, g_pk, c->st, c->tab, c->d_tw, F, c->hist_len, c->cfg.er_ring_frames, parts, p_off, fd_gt == G_FX_HRTF && c->fused_streams ? c->d_cursors : nullptr, c->d_fade_env, fresh, fd_gt == G_FX_HRTF ? job : gas_deferred_reduce());
+				e = gas_launch_hrtf_ols(c->stream, fd_gt == G_FX_ER_HRTF, (c->cfg.flags & GAS_FLAG_HRTF_CROSSFADE) != 0, (c->cfg.flags & (GAS_FLAG_DIRECTION_RUNS | GAS_FLAG_DIRECTION_ORDER)) != 0, g_fd, g_pk, c->st, c->tab, c->d_tw, F, c->hist_len, c->cfg.er_ring_frames, parts, p_off, fd_gt == G_FX_HRTF && c->fused_streams ? c->d_cursors : nullptr, c->d_fade_env, fresh, fd_gt == G_FX_HRTF ? job : gas_deferred_reduce());
 				if (fd_gt == G_FX_HRTF) {
+					carried_bytes = job.partials ? ((uint64_t)job.p_count + 1) * job.elems * sizeof(float) : 0;
 					job = gas_deferred_reduce();
 				}
 			} break;
@@ -530,7 +532,7 @@ int run_groups(gas_ctx *c, const gas_audio_frame *d_src, const uint32_t *d_slots
 		if (timed) {
 			GAS_HIP(c, hipEventRecord(c->ev[c->ev_used + 1], c->stream));
 			c->ev_used += 2;
-			c->prof_bytes = group_bytes(c, gt, gr.count);
+			c->prof_bytes = group_bytes(c, gt, gr.count) + carried_bytes;
 			if ((gt == G_FX_HRTF || gt == G_FX_ER_HRTF) && groups[gt + 1].count > 0) {
 				// the exact-peak sources ride in the same launch: add their per-source bytes (table/mix terms counted once)
 				c->prof_bytes += group_bytes(c, gt + 1, groups[gt + 1].count) - group_bytes(c, gt + 1, 0);

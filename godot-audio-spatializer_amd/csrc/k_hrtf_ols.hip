@@ -441,7 +441,7 @@ struct HrtfLds {
 	static constexpr int TOTAL_F2 = PEAKS ? WAVES * LDS_F2_PER_WAVE : (FD_F2 + 2 * LDS_F2_HALF + F > WAVES * LDS_F2_PER_WAVE ? FD_F2 + 2 * LDS_F2_HALF + F : WAVES * LDS_F2_PER_WAVE);
 };
 
-template <int SQ, bool WITH_ER, bool PEAKS, bool SRC_PCM, bool XFADE>
+template <int SQ, bool WITH_ER, bool PEAKS, bool SRC_PCM, bool XFADE, bool RUNS = false>
 __device__ __forceinline__ void hrtf_body(float2 *lds_all, const uint32_t wg, const gas_group_args &g, const gas_dev_state &st, const gas_hrtf_table &tab, const float2 *__restrict__ tw, uint32_t spw, uint32_t er_R, float *__restrict__ my_partial, gas_cursor *__restrict__ cursors, const float *__restrict__ fade_env, const gas_params *__restrict__ fresh, gas_audio_frame *__restrict__ rows_out = nullptr, const gas_deferred_reduce job = gas_deferred_reduce(), float4 *job_red = nullptr, uint32_t job_col = 0, uint32_t job_nwg = 1) {
 	static_assert(!(WITH_ER && SRC_PCM), "the early-reflection prologue reads float rows");
 	constexpr int FQ = 2 * SQ; // F / 64
@@ -498,9 +498,11 @@ __device__ __forceinline__ void hrtf_body(float2 *lds_all, const uint32_t wg, co
 		bYR[j] = make_float2(0.0f, 0.0f);
 	}
 
-	// PEAKS = false: time-domain sum of the windows of a run of sources that share one HRIR direction
+	// PEAKS = false, RUNS: time-domain sum of the windows of a run of sources that share one HRIR direction
 	// (sum_s Z_s H[d] = FFT(sum_s z_s) H[d]): the forward FFT, the table row and the spectral products are paid per
-	// run, not per source.  Runs are long when the context ordered the group by direction (g.order).
+	// run, not per source.  Runs are long when the caller keeps its list grouped by direction or the context ordered
+	// the group (g.order).  Without RUNS every source is transformed on its own: the run bookkeeping costs 4-5 % on
+	// lists without runs (measured), so it is a launch-time choice (GAS_FLAG_DIRECTION_RUNS / _ORDER).
 	float2 zs[8];
 #pragma unroll
 	for (int j = 0; j < 8; j++) {
@@ -763,7 +765,7 @@ __device__ __forceinline__ void hrtf_body(float2 *lds_all, const uint32_t wg, co
 			}
 			// the run ends with the wave's sources or when the direction changes; the cross-fade pairs every source
 			// with its own previous direction, so it transforms source by source
-			const bool flush = XFADE || !has_next || mn.dir != m.dir; // wave-uniform
+			const bool flush = !RUNS || XFADE || !has_next || mn.dir != m.dir; // wave-uniform; constant without RUNS
 			if (flush) {
 				fft512<false>(zs, t1, t2, lds, lane);
 				finish_spectra(lane, hs);
@@ -913,14 +915,14 @@ __device__ __forceinline__ void hrtf_body(float2 *lds_all, const uint32_t wg, co
 
 // One launch per callback for every HRTF source: workgroups [0, wgs_fd) run the frequency-domain body over
 // g_fd, the rest run the exact-peak body over g_pk (the draining playbacks).
-template <int SQ, bool WITH_ER, bool SRC_PCM, bool XFADE>
+template <int SQ, bool WITH_ER, bool SRC_PCM, bool XFADE, bool RUNS>
 __global__ __launch_bounds__(WAVES * 64, GAS_HRTF_WAVES_PER_SIMD) void k_hrtf_ols(gas_group_args g_fd, gas_group_args g_pk, uint32_t wgs_fd, gas_dev_state st, gas_hrtf_table tab, const float2 *__restrict__ tw, uint32_t spw_fd, uint32_t spw_pk, uint32_t er_R, float *__restrict__ partials, uint32_t p_offset, gas_cursor *__restrict__ cursors, const float *__restrict__ fade_env, const gas_params *__restrict__ fresh, gas_deferred_reduce job) {
 	constexpr int LDS_F2 = HrtfLds<SQ, false>::TOTAL_F2 > HrtfLds<SQ, true>::TOTAL_F2 ? HrtfLds<SQ, false>::TOTAL_F2 : HrtfLds<SQ, true>::TOTAL_F2;
 	__shared__ float2 lds_all[LDS_F2];
 	__shared__ float4 job_red[GAS_HRTF_JOB_WAVES * 64];
 	float *my_partial = partials + ((size_t)p_offset + blockIdx.x) * (size_t)(2 * SQ * 64 * 2);
 	if (blockIdx.x < wgs_fd) {
-		hrtf_body<SQ, WITH_ER, false, SRC_PCM, XFADE>(lds_all, blockIdx.x, g_fd, st, tab, tw, spw_fd, er_R, my_partial, cursors, fade_env, fresh, nullptr, job, job_red, blockIdx.x, gridDim.x);
+		hrtf_body<SQ, WITH_ER, false, SRC_PCM, XFADE, RUNS>(lds_all, blockIdx.x, g_fd, st, tab, tw, spw_fd, er_R, my_partial, cursors, fade_env, fresh, nullptr, job, job_red, blockIdx.x, gridDim.x);
 	} else {
 		hrtf_body<SQ, WITH_ER, true, SRC_PCM, XFADE>(lds_all, blockIdx.x - wgs_fd, g_pk, st, tab, tw, spw_pk, er_R, my_partial, cursors, fade_env, fresh, nullptr, job, job_red, blockIdx.x, gridDim.x);
 	}
@@ -1148,7 +1150,7 @@ uint32_t gas_hrtf_partials(uint32_t n, uint32_t *sources_per_wave) {
 	return p.wgs_fd;
 }
 
-hipError_t gas_launch_hrtf_ols(hipStream_t stream, bool with_er, bool crossfade, const gas_group_args &g_fd, const gas_group_args &g_pk, const gas_dev_state &st, const gas_hrtf_table &tab, const float2 *twiddles, uint32_t frames, uint32_t hist_len, uint32_t er_ring_frames, float *partials, uint32_t p_offset, gas_cursor *cursors, const float *fade_env, const gas_params *fresh, const gas_deferred_reduce &job) {
+hipError_t gas_launch_hrtf_ols(hipStream_t stream, bool with_er, bool crossfade, bool runs, const gas_group_args &g_fd, const gas_group_args &g_pk, const gas_dev_state &st, const gas_hrtf_table &tab, const float2 *twiddles, uint32_t frames, uint32_t hist_len, uint32_t er_ring_frames, float *partials, uint32_t p_offset, gas_cursor *cursors, const float *fade_env, const gas_params *fresh, const gas_deferred_reduce &job) {
 	if (g_fd.n + g_pk.n == 0) {
 		return hipSuccess;
 	}
@@ -1159,8 +1161,14 @@ hipError_t gas_launch_hrtf_ols(hipStream_t stream, bool with_er, bool crossfade,
 	gas_hrtf_plan(g_fd.n, g_pk.n, &plan);
 	const uint32_t wgs_fd = plan.wgs_fd, spw_fd = plan.spw_fd, spw_pk = plan.spw_pk;
 	dim3 grid(plan.wgs_fd + plan.wgs_pk), block(WAVES * 64);
-#define GAS_HRTF_LAUNCH(SQv, ERv, PCMv, XFv) \
-	hipLaunchKernelGGL((k_hrtf_ols<SQv, ERv, PCMv, XFv>), grid, block, 0, stream, g_fd, g_pk, wgs_fd, st, tab, twiddles, spw_fd, spw_pk, er_ring_frames, partials, p_offset, cursors, fade_env, fresh, job)
+#define GAS_HRTF_LAUNCH2(SQv, ERv, PCMv, XFv, RNv) \
+	hipLaunchKernelGGL((k_hrtf_ols<SQv, ERv, PCMv, XFv, RNv>), grid, block, 0, stream, g_fd, g_pk, wgs_fd, st, tab, twiddles, spw_fd, spw_pk, er_ring_frames, partials, p_offset, cursors, fade_env, fresh, job)
+#define GAS_HRTF_LAUNCH(SQv, ERv, PCMv, XFv)          \
+	if (runs && !XFv) {                               \
+		GAS_HRTF_LAUNCH2(SQv, ERv, PCMv, false, true); \
+	} else {                                          \
+		GAS_HRTF_LAUNCH2(SQv, ERv, PCMv, XFv, false);  \
+	}
 #define GAS_HRTF_CASE3(SQv, XFv)                      \
 	if (with_er) {                                    \
 		GAS_HRTF_LAUNCH(SQv, true, false, XFv);       \
@@ -1188,6 +1196,7 @@ hipError_t gas_launch_hrtf_ols(hipStream_t stream, bool with_er, bool crossfade,
 #undef GAS_HRTF_CASE
 #undef GAS_HRTF_CASE3
 #undef GAS_HRTF_LAUNCH
+#undef GAS_HRTF_LAUNCH2
 	return hipGetLastError();
 }
 

@@ -103,11 +103,14 @@ typedef struct gas_config {
  * block with both HRIRs and blend old -> new with t = i/F (the analogue of the per-block volume lerp,
  * audio_spatializer_3d.cpp:591-592) instead of switching at the block boundary. */
 #define GAS_FLAG_HRTF_CROSSFADE 2u
-/* Frequency-domain HRTF sources that follow each other in the callback's list with the SAME hrtf_dir are always
- * summed before one forward FFT (a list kept grouped by direction costs ~15 % less).  With this flag the library
- * also builds that grouping itself (a device counting sort per 8192-source segment, re-run after every parameter
- * publish or list change).  Results are identical up to f32 summation order.  Pays only when parameters are
- * published much less often than callbacks run (measured: DESIGN.md 3.1); no effect with GAS_FLAG_HRTF_CROSSFADE. */
+/* HRTF sources whose hrtf_dir repeats can share one forward FFT (sum_s Z_s H[d] = FFT(sum_s z_s) H[d]).
+ * GAS_FLAG_DIRECTION_RUNS: the caller keeps sources with equal hrtf_dir adjacent in the callback's list (as far as
+ * it likes: any list is correct); frequency-domain sources then sum each run in the time domain before one FFT
+ * (measured 15-19 % less kernel time at 8 sources per direction; 4-5 % MORE on a list without runs, hence a flag).
+ * GAS_FLAG_DIRECTION_ORDER: the library builds the grouping itself (a device counting sort per 8192-source segment,
+ * re-run after every parameter publish or list change); implies _RUNS.  Pays only when parameters are published
+ * much less often than callbacks run.  Results are identical up to f32 summation order; neither
+ * flag has an effect together with GAS_FLAG_HRTF_CROSSFADE. */
 #define GAS_FLAG_DIRECTION_ORDER 4u
 /* Throughput mode for callers that queue many callbacks (offline rendering, benchmarks): the final sum of the
  * per-workgroup partial mixes of gas_process_block(GAS_MEM_DEVICE) is not launched as its own kernel; it is carried
@@ -118,6 +121,7 @@ typedef struct gas_config {
  * callback contains HRTF sources; other callbacks are summed immediately.  Same operations in the same order:
  * results are bitwise identical to the ordered mode.  A synchronous audio callback gains nothing from it. */
 #define GAS_FLAG_PIPELINED_MIX 8u
+#define GAS_FLAG_DIRECTION_RUNS 16u /* see GAS_FLAG_DIRECTION_ORDER */
 
 /* SpatializerParameters (spatializer_parameters.h:39-67) + SpatializerParameters3D
  * (audio_spatializer_3d.h:61-83) as one 128-byte POD, plus the per-block effect

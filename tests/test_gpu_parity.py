@@ -214,3 +214,34 @@ def test_hrtf_direction_ordered_groups(gas, ob, n, dirs, chain, frames, ring):
         np.testing.assert_allclose(peaks[draining[perm]], rpeaks[perm][draining[perm]], rtol=2e-5, atol=1e-7)
         assert np.all(np.isposinf(peaks[~draining[perm]]))
     ctx.close()
+
+
+@pytest.mark.parametrize("chain,frames,ring", [((3,), 512, 0), ((2, 3), 256, 4096)])
+def test_hrtf_direction_runs_in_the_callers_list(gas, ob, chain, frames, ring):
+    """GAS_FLAG_DIRECTION_RUNS: the caller's list has runs of equal directions (here: long runs, runs of one, and a
+    run that crosses wave and workgroup boundaries); each run is summed before one forward FFT."""
+    from godot_audio_spatializer_amd import synth
+
+    rng = np.random.default_rng(5)
+    n, dirs = 333, 24
+    hrir = synth.synthetic_hrir(np.random.default_rng(7), dirs=dirs)
+    K = gas.capi
+    ctx = gas.SpatializerContext(max_sources=n, frames=frames, er_ring_frames=ring, flags=K.FLAG_PEAKS_DRAINING_ONLY | K.FLAG_DIRECTION_RUNS)
+    ctx.hrtf_load(hrir)
+    slots = ctx.source_alloc_many(n, K.KIND_EFFECT, chain)
+    ctx.source_set_draining(slots[100], True)
+    ora = ob.BatchOracle(ob.KIND_EFFECT, n, frames, chain=chain, hrir=hrir, er_ring_frames=max(ring, 1))
+    for b in range(5):
+        p = synth.draw_params(rng, n, dirs=dirs, ring_frames=max(ring, 2 * frames), frames=frames)
+        d = np.sort(p["hrtf_dir"])
+        d[:90] = 3  # one run across many waves
+        if b % 2:
+            d[200:] = rng.integers(0, dirs, n - 200)  # runs of one behind it
+        p["hrtf_dir"] = d
+        ctx.params_publish_batch(slots, p)
+        src = synth.draw_sources(rng, n, frames)
+        mix, peaks = ctx.process_block(src, slots)
+        _, rpeaks, r64 = ora.block(p.astype(ob.PARAMS_DTYPE), src, want64=True)
+        assert rel_rms(mix[0], r64[0]) <= TOL, f"block {b}"
+        np.testing.assert_allclose(peaks[100], rpeaks[100], rtol=2e-5, atol=1e-7)
+    ctx.close()
