@@ -34,7 +34,7 @@ HBM_PEAK = 8.0e12  # MI355X_MICROARCH.md: 8 TB/s spec
 N_SRC_BUFFERS_BYTES = 320 << 20  # rotate source buffers over > 256 MiB so the Infinity Cache cannot hold them
 
 
-def pmc_traffic(kernel, workload, n_local, peaks):
+def pmc_traffic(kernel, workload, n_local, peaks, pipelined):
     """HBM bytes per launch from the committed rocprofv3 PMC passes of this same command (profiles/*_pmc.json,
     written by tools/profile_bench.sh; FETCH_SIZE x2 + WRITE_SIZE), or None."""
     import glob
@@ -45,7 +45,7 @@ def pmc_traffic(kernel, workload, n_local, peaks):
             rec = json.load(open(path))
         except (OSError, ValueError):
             continue
-        if rec.get("kernel") == kernel and rec.get("workload") == workload and rec.get("sources_per_gpu") == n_local and rec.get("peaks") == peaks:
+        if rec.get("kernel") == kernel and rec.get("workload") == workload and rec.get("sources_per_gpu") == n_local and rec.get("peaks") == peaks and bool(rec.get("pipelined_mix", False)) == pipelined:
             best = (rec["traffic_bytes_per_launch"], os.path.basename(path))
     return best
 
@@ -333,7 +333,7 @@ def main():
         }
 
     if rank == 0:
-        t = pmc_traffic(result["roofline"]["kernel"], desc, n_local, result["config"].get("peaks"))
+        t = pmc_traffic(result["roofline"]["kernel"], desc, n_local, result["config"].get("peaks"), bool(result["config"].get("pipelined_mix")))
         if t:
             result["roofline"]["traffic"] = t[0] / 1e9 * 1e9  # bytes per launch
             result["roofline"]["traffic_source"] = "profiles/" + t[1] + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command; FETCH x2 on gfx950)"

@@ -1657,15 +1657,14 @@ int gas_profile_enable(gas_ctx *c, int on) {
 		}
 	}
 	if (on) {
-		// An event pair around a launch reads the kernel plus marker/dispatch overhead.  Calibrate that
-		// overhead with an empty kernel (minimum of 16 tries; the empty dispatch's own sub-microsecond
-		// execution is left in, so the corrected figure errs on the slow side) -- with it the event
-		// figure tracks the rocprofv3 kernel trace of the same run to within ~5-10 %.
+		// An event pair around a launch reads the launch's span on the GPU timeline plus the cost of the second
+		// marker.  Only the marker is calibrated away (an empty bracket, minimum of 16 tries): the dispatch ramp of
+		// the kernel itself stays in, exactly as rocprofv3's kernel trace counts it (an empty kernel reads 3-4 us
+		// there), so the two figures of one run agree and neither flatters the kernel.
 		GAS_HIP(c, hipStreamSynchronize(c->stream));
 		double best = 1e9;
 		for (int i = 0; i < 16; i++) {
 			GAS_HIP(c, hipEventRecord(c->ev[0], c->stream));
-			GAS_HIP(c, gas_launch_noop(c->stream));
 			GAS_HIP(c, hipEventRecord(c->ev[1], c->stream));
 			GAS_HIP(c, hipEventSynchronize(c->ev[1]));
 			float ms = 0.0f;

@@ -57,7 +57,7 @@ struct gas_group_args {
 
 // GAS_FLAG_PIPELINED_MIX: the final sum of the PREVIOUS callback's partial mixes (exactly k_mix_reduce's job for one
 // channel pair), carried out by otherwise idle waves of this callback's k_hrtf_ols launch.  partials == nullptr: none.
-#define GAS_HRTF_JOB_WAVES 6 // waves of a k_hrtf_ols workgroup that can each sum one output column of the previous callback
+#define GAS_HRTF_JOB_WAVES 4 // waves of a k_hrtf_ols workgroup that can each sum one output column of the previous callback
 struct gas_deferred_reduce {
 	const float *partials = nullptr; // [p_count][elems]
 	uint32_t p_count = 0;

@@ -464,15 +464,18 @@ __device__ __forceinline__ void hrtf_body(float2 *lds_all, const uint32_t wg, co
 	}
 
 	// GAS_FLAG_PIPELINED_MIX: one wave also sums the previous callback's partial mixes for one output column
-	// (waves 2 .. WAVES-1, idle while waves 0 and 1 run the frequency-domain epilogue's inverse FFTs, take columns
-	// wg, wg + n_wg, ...: GAS_HRTF_JOB_WAVES columns per workgroup at most)
+	// (waves 2 .. 5, idle while waves 0 and 1 run the frequency-domain epilogue's inverse FFTs, take one column each)
 	constexpr bool JOB_OK = !WITH_ER && !SRC_PCM && !XFADE; // register budget: the plain chain only
 	float4 jr[JOB_ROWS];
 	bool job_mine = false;
 	if constexpr (JOB_OK) {
-		job_col = job_col + (uint32_t)(wave - 2) * job_nwg;
-		job_red += (wave >= 2 ? wave - 2 : 0) * 64;
-		job_mine = job.partials != nullptr && wave >= 2 && job_col < job.elems / 4; // wave-uniform
+		// Column -> (workgroup, wave): the 8 float4 columns of one 128-byte line go to waves 2..5 of two workgroups
+		// of the same XCD (workgroups are dealt round-robin over the 8 XCDs), so every line of the partials is pulled
+		// into one L2 only: job_col holds the workgroup index w; XCD x = w % 8, i = w / 8.
+		const uint32_t jw = (uint32_t)(wave - 2), jx = job_col & 7, ji = job_col >> 3;
+		job_col = (((ji >> 1) * 8 + jx) * 8) + (ji & 1) * 4 + jw;
+		job_red += (jw < GAS_HRTF_JOB_WAVES ? jw : 0) * 64;
+		job_mine = job.partials != nullptr && wave >= 2 && jw < GAS_HRTF_JOB_WAVES && job_col < job.elems / 4; // wave-uniform
 		if (job_mine) {
 			job_issue(job, job_col, lane, jr);
 		}
