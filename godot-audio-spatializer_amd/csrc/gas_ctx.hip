@@ -244,7 +244,7 @@ void plan_partials(const Group *groups, const std::vector<ChainRange> &ranges, u
 	for (int gt = G_3D_MIX; gt <= G_FX_SHELF; gt++) {
 		pcount[gt] = groups[gt].count ? gas_biquad_partials(groups[gt].count) : 0;
 	}
-	pcount[G_FX_ER] = groups[G_FX_ER].count ? gas_hrtf_partials(groups[G_FX_ER].count, nullptr) : 0;
+	pcount[G_FX_ER] = groups[G_FX_ER].count ? gas_hrtf_partials(groups[G_FX_ER].count) : 0;
 	for (int gt : { (int)G_FX_HRTF, (int)G_FX_ER_HRTF }) {
 		gas_hrtf_launch_plan p;
 		gas_hrtf_plan(groups[gt].count, groups[gt + 1].count, &p);
@@ -253,7 +253,7 @@ void plan_partials(const Group *groups, const std::vector<ChainRange> &ranges, u
 	}
 	if (groups[G_FX_GENERIC].count) {
 		for (const ChainRange &r : ranges) {
-			pcount[G_FX_GENERIC] += gas_hrtf_partials(r.count, nullptr);
+			pcount[G_FX_GENERIC] += gas_hrtf_partials(r.count);
 		}
 	}
 }
@@ -521,7 +521,7 @@ int run_groups(gas_ctx *c, const gas_audio_frame *d_src, const uint32_t *d_slots
 						fin.rows = peak_rows; // peaks go to the callback's row of each source
 						e = gas_launch_rows_accumulate(c->stream, fin, F, parts, pp);
 					}
-					pp += gas_hrtf_partials(r.count, nullptr);
+					pp += gas_hrtf_partials(r.count);
 				}
 			} break;
 			case G_FX_ER:

@@ -84,11 +84,10 @@ uint32_t gas_biquad_partials(uint32_t n); // P for n sources
 hipError_t gas_launch_biquad_mix(hipStream_t stream, int mode, const gas_group_args &g, const gas_dev_state &st, uint32_t frames, uint32_t channel_begin, uint32_t channel_count, float mix_rate, float *partials, uint32_t p_offset, uint32_t p_stride, float *rows_out = nullptr /* non-null: per-source rows instead of the partial mix */);
 
 struct gas_hrtf_launch_plan {
-	uint32_t spw_fd, spw_pk; // sources per wave
 	uint32_t wgs_fd, wgs_pk; // workgroups = partial mixes written
 };
 void gas_hrtf_plan(uint32_t n_fd, uint32_t n_pk, gas_hrtf_launch_plan *plan);
-uint32_t gas_hrtf_partials(uint32_t n, uint32_t *sources_per_wave); // plan for a single-path launch (k_er_only)
+uint32_t gas_hrtf_partials(uint32_t n); // workgroups of a single-path launch (k_er_only, k_hrtf_rows, k_rows_accumulate)
 hipError_t gas_launch_hrtf_ols(hipStream_t stream, bool with_er, bool crossfade, bool runs /* sum runs of equal directions before the FFT */, const gas_group_args &g_fd, const gas_group_args &g_pk, const gas_dev_state &st, const gas_hrtf_table &tab, const float2 *twiddles, uint32_t frames, uint32_t hist_len, uint32_t er_ring_frames, float *partials, uint32_t p_offset, gas_cursor *cursors /* non-null: sample the bound streams in the kernel */, const float *fade_env, const gas_params *fresh /* non-null: unscattered parameter rows in row order */, const gas_deferred_reduce &job = gas_deferred_reduce());
 hipError_t gas_launch_er_only(hipStream_t stream, const gas_group_args &g, const gas_dev_state &st, uint32_t frames, uint32_t er_ring_frames, float *partials, uint32_t p_offset, uint32_t p_stride, gas_audio_frame *rows_out = nullptr);
 // stages of a general effect chain (rows in -> rows out) and its final mix

@@ -51,6 +51,9 @@ __device__ __forceinline__ float2 cmulc(float2 a, float2 b) { // a * conj(b)
 }
 // Once-touched streams (source rows, history) bypass the caches' retention so they do not evict the HRIR
 // spectra table, which is the only data re-read across sources (MI355X_MICROARCH.md nt-weights row).
+#ifndef GAS_ABL
+#define GAS_ABL 0 // timing experiments only (results are wrong): 1 no table loads, 2 no history traffic, 4 no forward FFT, 8 no row loads, 16 no twiddle loads, 32 no frequency-domain epilogue, 64 no per-source state writes
+#endif
 #ifdef GAS_USE_NT // measured: no effect on MI355X for this kernel (profiles/r01_notes.md); kept as a switch
 #define GAS_NT_LOAD(p) __builtin_nontemporal_load(p)
 #define GAS_NT_STORE(v, p) __builtin_nontemporal_store(v, p)
@@ -287,7 +290,7 @@ __device__ __forceinline__ void load_window(const gas_group_args &g, const SrcMe
 	if constexpr (!SRC_PCM) {
 #pragma unroll
 		for (int q = 0; q < FQ; q++) {
-			raw[q] = nt_load_frame(&g.src[(size_t)m.row * F + lane + 64 * q]);
+			raw[q] = (GAS_ABL & 8) ? gas_audio_frame{ (float)lane, (float)m.row } : nt_load_frame(&g.src[(size_t)m.row * F + lane + 64 * q]);
 		}
 	} else {
 		const void *p = m.hf ? m.pcm : static_cast<const void *>(fade_env); // any readable address when nothing plays
@@ -356,6 +359,13 @@ __device__ __forceinline__ void load_window(const gas_group_args &g, const SrcMe
 // are fetched as bin 512 - k -- the same 4 KiB, mirrored addressing -- and conjugated.  This halves the
 // table footprint (4 MiB at 1024 directions = one XCD L2) and its L2 -> CU traffic per source.
 __device__ __forceinline__ void issue_spectra(const float4 *__restrict__ spec, uint32_t dir, int lane, float4 (&hs)[8]) {
+	if (GAS_ABL & 1) {
+#pragma unroll
+		for (int j = 0; j < 8; j++) {
+			hs[j] = make_float4(1.0f, 0.5f, 0.25f, (float)dir);
+		}
+		return;
+	}
 	const float4 *base = spec + (size_t)dir * 256;
 #pragma unroll
 	for (int j = 0; j < 4; j++) {
@@ -420,6 +430,14 @@ __device__ __forceinline__ void job_finish(const gas_deferred_reduce &j, uint32_
 	}
 }
 
+// Sources [first, last) of wave `gw` out of `n_waves`: an even split (the first n % n_waves waves take one more), so
+// every planned workgroup has work -- a uniform ceil(n / n_waves) per wave left 21 % of the CUs idle at 8064 sources.
+__device__ __forceinline__ void wave_range(uint32_t n, uint32_t gw, uint32_t n_waves, uint32_t &first, uint32_t &last) {
+	const uint32_t base = n / n_waves, rem = n % n_waves;
+	first = gw * base + (gw < rem ? gw : rem);
+	last = first + base + (gw < rem ? 1u : 0u);
+}
+
 // SQ = S/64 = F/128: 4 for F = 512, 2 for F = 256.
 //
 // PEAKS = true : every source gets its own pair of inverse FFTs, so its output peak (the input of the
@@ -442,7 +460,7 @@ struct HrtfLds {
 };
 
 template <int SQ, bool WITH_ER, bool PEAKS, bool SRC_PCM, bool XFADE, bool RUNS = false>
-__device__ __forceinline__ void hrtf_body(float2 *lds_all, const uint32_t wg, const gas_group_args &g, const gas_dev_state &st, const gas_hrtf_table &tab, const float2 *__restrict__ tw, uint32_t spw, uint32_t er_R, float *__restrict__ my_partial, gas_cursor *__restrict__ cursors, const float *__restrict__ fade_env, const gas_params *__restrict__ fresh, gas_audio_frame *__restrict__ rows_out = nullptr, const gas_deferred_reduce job = gas_deferred_reduce(), float4 *job_red = nullptr, uint32_t job_col = 0, uint32_t job_nwg = 1) {
+__device__ __forceinline__ void hrtf_body(float2 *lds_all, const uint32_t wg, const gas_group_args &g, const gas_dev_state &st, const gas_hrtf_table &tab, const float2 *__restrict__ tw, uint32_t n_wgs, uint32_t er_R, float *__restrict__ my_partial, gas_cursor *__restrict__ cursors, const float *__restrict__ fade_env, const gas_params *__restrict__ fresh, gas_audio_frame *__restrict__ rows_out = nullptr, const gas_deferred_reduce job = gas_deferred_reduce(), float4 *job_red = nullptr, uint32_t job_col = 0, uint32_t job_nwg = 1) {
 	static_assert(!(WITH_ER && SRC_PCM), "the early-reflection prologue reads float rows");
 	constexpr int FQ = 2 * SQ; // F / 64
 	constexpr int HQ = 8 - SQ; // hist_len / 64
@@ -459,8 +477,8 @@ __device__ __forceinline__ void hrtf_body(float2 *lds_all, const uint32_t wg, co
 	float2 t1[8], t2[8];
 #pragma unroll
 	for (int k = 0; k < 8; k++) {
-		t1[k] = tw[lane * 16 + k];
-		t2[k] = tw[lane * 16 + 8 + k];
+		t1[k] = (GAS_ABL & 16) ? make_float2(0.001f * (float)(lane + k), 1.0f) : tw[k * 64 + lane];
+		t2[k] = (GAS_ABL & 16) ? make_float2(1.0f, 0.002f * (float)(lane - k)) : tw[(8 + k) * 64 + lane];
 	}
 
 	// GAS_FLAG_PIPELINED_MIX: one wave also sums the previous callback's partial mixes for one output column
@@ -512,8 +530,8 @@ __device__ __forceinline__ void hrtf_body(float2 *lds_all, const uint32_t wg, co
 		zs[j] = make_float2(0.0f, 0.0f);
 	}
 
-	const uint32_t first = (wg * WAVES + wave) * spw;
-	const uint32_t last = first + spw < g.n ? first + spw : g.n;
+	uint32_t first, last;
+	wave_range(g.n, wg * WAVES + wave, n_wgs * WAVES, first, last);
 
 	// in-flight buffers of the software pipeline
 	float4 hs[8]; // spectra (HL.re, HL.im, HR.re, HR.im) of bins lane + 64 j
@@ -527,7 +545,7 @@ __device__ __forceinline__ void hrtf_body(float2 *lds_all, const uint32_t wg, co
 	//            source's history and frames
 	//   level 3  the first source's spectra (consumed after the forward FFT, so they arrive under it)
 	LaneMeta lm{};
-	const bool have = first + lane < last; // spw <= 64: one lane per source of this wave
+	const bool have = first + lane < last; // <= 64 sources per wave (gas_hrtf_plan): one lane per source of this wave
 	if (have) {
 		const uint32_t e = g.order ? g.order[first + lane] : first + lane; // direction order (k_dir_order) or entry order
 		lm.slot = g.slots ? g.slots[e] : g.slot_base + e;
@@ -568,7 +586,7 @@ __device__ __forceinline__ void hrtf_body(float2 *lds_all, const uint32_t wg, co
 				ms.row = (uint32_t)__builtin_amdgcn_readlane((int)lm.row, s);
 #pragma unroll
 				for (int q = 0; q < HQ; q++) {
-					rawh[s][q] = GAS_NT_LOAD(&st.hrtf_hist[(size_t)ms.slot * HL + lane + 64 * q]);
+					rawh[s][q] = (GAS_ABL & 2) ? (float)lane : GAS_NT_LOAD(&st.hrtf_hist[(size_t)ms.slot * HL + lane + 64 * q]);
 				}
 				if constexpr (!WITH_ER && !SRC_PCM) {
 					load_window<false, FQ>(g, ms, lane, fade_env, raw[s]); // needs the row only
@@ -657,9 +675,11 @@ __device__ __forceinline__ void hrtf_body(float2 *lds_all, const uint32_t wg, co
 		// new history = x_full[F .. F + HL)
 #pragma unroll
 		for (int q = 0; q < HQ; q++) {
-			GAS_NT_STORE(xq[FQ + q], &st.hrtf_hist[(size_t)m.slot * HL + lane + 64 * q]);
+			if (!(GAS_ABL & 2)) {
+				GAS_NT_STORE(xq[FQ + q], &st.hrtf_hist[(size_t)m.slot * HL + lane + 64 * q]);
+			}
 		}
-		if (lane == 0) {
+		if (lane == 0 && !(GAS_ABL & 64)) {
 			st.hrtf_prev_gain[m.slot] = m.g1;
 			if constexpr (XFADE) {
 				st.hrtf_prev_dir[m.slot] = m.dir + 1;
@@ -677,7 +697,7 @@ __device__ __forceinline__ void hrtf_body(float2 *lds_all, const uint32_t wg, co
 		if (has_ahead) {
 #pragma unroll
 			for (int q = 0; q < HQ; q++) {
-				rawh[s][q] = GAS_NT_LOAD(&st.hrtf_hist[(size_t)ma.slot * HL + lane + 64 * q]);
+				rawh[s][q] = (GAS_ABL & 2) ? (float)lane : GAS_NT_LOAD(&st.hrtf_hist[(size_t)ma.slot * HL + lane + 64 * q]);
 			}
 			if constexpr (!WITH_ER) {
 				load_window<SRC_PCM, FQ>(g, ma, lane, fade_env, raw[s]);
@@ -770,7 +790,9 @@ __device__ __forceinline__ void hrtf_body(float2 *lds_all, const uint32_t wg, co
 			// with its own previous direction, so it transforms source by source
 			const bool flush = !RUNS || XFADE || !has_next || mn.dir != m.dir; // wave-uniform; constant without RUNS
 			if (flush) {
-				fft512<false>(zs, t1, t2, lds, lane);
+				if (!(GAS_ABL & 4)) {
+					fft512<false>(zs, t1, t2, lds, lane);
+				}
 				finish_spectra(lane, hs);
 #pragma unroll
 				for (int j = 0; j < 8; j++) {
@@ -804,7 +826,7 @@ __device__ __forceinline__ void hrtf_body(float2 *lds_all, const uint32_t wg, co
 					issue_spectra(tab.spec, mn.dir, lane, hs);
 				}
 			}
-			if (lane == 0) {
+			if (lane == 0 && !(GAS_ABL & 64)) {
 				g.peaks[(size_t)m.row * 2] = __builtin_inff();
 				g.peaks[(size_t)m.row * 2 + 1] = __builtin_inff();
 			}
@@ -842,6 +864,15 @@ __device__ __forceinline__ void hrtf_body(float2 *lds_all, const uint32_t wg, co
 		// spectra of all waves -> fd[wave][ear][j][lane]; then wave 0 transforms the left ear's sum and
 		// wave 1 the right ear's, and the workgroup stores one interleaved time-domain partial.  With XFADE the
 		// same round runs twice: new-direction sums weighted by t = f/F, old-direction sums by 1 - t.
+		if (GAS_ABL & 32) {
+#pragma unroll
+			for (int j = 0; j < 8; j++) {
+				if (wave == 0 && aYL[j].x + aYR[j].y == 12345.0f) {
+					my_partial[lane] = aYL[j].x;
+				}
+			}
+			return;
+		}
 		float2 *fd = lds_all;
 		float *outp = reinterpret_cast<float *>(lds_all + FD_F2 + 2 * LDS_F2_HALF);
 		constexpr int ROUNDS = XFADE ? 2 : 1;
@@ -919,29 +950,29 @@ __device__ __forceinline__ void hrtf_body(float2 *lds_all, const uint32_t wg, co
 // One launch per callback for every HRTF source: workgroups [0, wgs_fd) run the frequency-domain body over
 // g_fd, the rest run the exact-peak body over g_pk (the draining playbacks).
 template <int SQ, bool WITH_ER, bool SRC_PCM, bool XFADE, bool RUNS>
-__global__ __launch_bounds__(WAVES * 64, GAS_HRTF_WAVES_PER_SIMD) void k_hrtf_ols(gas_group_args g_fd, gas_group_args g_pk, uint32_t wgs_fd, gas_dev_state st, gas_hrtf_table tab, const float2 *__restrict__ tw, uint32_t spw_fd, uint32_t spw_pk, uint32_t er_R, float *__restrict__ partials, uint32_t p_offset, gas_cursor *__restrict__ cursors, const float *__restrict__ fade_env, const gas_params *__restrict__ fresh, gas_deferred_reduce job) {
+__global__ __launch_bounds__(WAVES * 64, GAS_HRTF_WAVES_PER_SIMD) void k_hrtf_ols(gas_group_args g_fd, gas_group_args g_pk, uint32_t wgs_fd, gas_dev_state st, gas_hrtf_table tab, const float2 *__restrict__ tw, uint32_t er_R, float *__restrict__ partials, uint32_t p_offset, gas_cursor *__restrict__ cursors, const float *__restrict__ fade_env, const gas_params *__restrict__ fresh, gas_deferred_reduce job) {
 	constexpr int LDS_F2 = HrtfLds<SQ, false>::TOTAL_F2 > HrtfLds<SQ, true>::TOTAL_F2 ? HrtfLds<SQ, false>::TOTAL_F2 : HrtfLds<SQ, true>::TOTAL_F2;
 	__shared__ float2 lds_all[LDS_F2];
 	__shared__ float4 job_red[GAS_HRTF_JOB_WAVES * 64];
 	float *my_partial = partials + ((size_t)p_offset + blockIdx.x) * (size_t)(2 * SQ * 64 * 2);
 	if (blockIdx.x < wgs_fd) {
-		hrtf_body<SQ, WITH_ER, false, SRC_PCM, XFADE, RUNS>(lds_all, blockIdx.x, g_fd, st, tab, tw, spw_fd, er_R, my_partial, cursors, fade_env, fresh, nullptr, job, job_red, blockIdx.x, gridDim.x);
+		hrtf_body<SQ, WITH_ER, false, SRC_PCM, XFADE, RUNS>(lds_all, blockIdx.x, g_fd, st, tab, tw, wgs_fd, er_R, my_partial, cursors, fade_env, fresh, nullptr, job, job_red, blockIdx.x, gridDim.x);
 	} else {
-		hrtf_body<SQ, WITH_ER, true, SRC_PCM, XFADE>(lds_all, blockIdx.x - wgs_fd, g_pk, st, tab, tw, spw_pk, er_R, my_partial, cursors, fade_env, fresh, nullptr, job, job_red, blockIdx.x, gridDim.x);
+		hrtf_body<SQ, WITH_ER, true, SRC_PCM, XFADE>(lds_all, blockIdx.x - wgs_fd, g_pk, st, tab, tw, gridDim.x - wgs_fd, er_R, my_partial, cursors, fade_env, fresh, nullptr, job, job_red, blockIdx.x, gridDim.x);
 	}
 }
 
 // One HRTF stage of a general effect chain: stereo rows in (mono downmix inside), per-source stereo rows out.
 template <int SQ, bool XFADE>
-__global__ __launch_bounds__(WAVES * 64, GAS_HRTF_WAVES_PER_SIMD) void k_hrtf_rows(gas_group_args g, gas_dev_state st, gas_hrtf_table tab, const float2 *__restrict__ tw, uint32_t spw, gas_audio_frame *__restrict__ rows_out) {
+__global__ __launch_bounds__(WAVES * 64, GAS_HRTF_WAVES_PER_SIMD) void k_hrtf_rows(gas_group_args g, gas_dev_state st, gas_hrtf_table tab, const float2 *__restrict__ tw, gas_audio_frame *__restrict__ rows_out) {
 	__shared__ float2 lds_all[HrtfLds<SQ, true>::TOTAL_F2];
-	hrtf_body<SQ, false, true, false, XFADE>(lds_all, blockIdx.x, g, st, tab, tw, spw, 0, nullptr, nullptr, nullptr, nullptr, rows_out);
+	hrtf_body<SQ, false, true, false, XFADE>(lds_all, blockIdx.x, g, st, tab, tw, gridDim.x, 0, nullptr, nullptr, nullptr, nullptr, rows_out);
 }
 
 // The last stage of a general chain left per-source rows: add them into this workgroup's partial mix and take each
 // source's peak (audio_spatializer.cpp:449-461).  Wave = source, lane = frame, like k_er_only without the taps.
 template <int FQ>
-__global__ __launch_bounds__(WAVES * 64) void k_rows_accumulate(gas_group_args g, uint32_t spw, float *__restrict__ partials, uint32_t p_offset) {
+__global__ __launch_bounds__(WAVES * 64) void k_rows_accumulate(gas_group_args g, float *__restrict__ partials, uint32_t p_offset) {
 	constexpr uint32_t F = FQ * 64;
 	__shared__ float red_all[WAVES * F * 2];
 	const int lane = threadIdx.x & 63;
@@ -952,8 +983,8 @@ __global__ __launch_bounds__(WAVES * 64) void k_rows_accumulate(gas_group_args g
 		accL[t] = 0.0f;
 		accR[t] = 0.0f;
 	}
-	const uint32_t first = (blockIdx.x * WAVES + wave) * spw;
-	const uint32_t last = first + spw < g.n ? first + spw : g.n;
+	uint32_t first, last;
+	wave_range(g.n, blockIdx.x * WAVES + wave, gridDim.x * WAVES, first, last);
 	for (uint32_t e = first; e < last; e++) {
 		const uint32_t row = g.rows ? g.rows[e] : e; // where this source's peak goes
 		float pkl = 0.0f, pkr = 0.0f;
@@ -1001,8 +1032,8 @@ __global__ __launch_bounds__(64) void k_hrtf_table(const float *__restrict__ hri
 	float2 t1[8], t2[8];
 #pragma unroll
 	for (int k = 0; k < 8; k++) {
-		t1[k] = tw[lane * 16 + k];
-		t2[k] = tw[lane * 16 + 8 + k];
+		t1[k] = tw[k * 64 + lane];
+		t2[k] = tw[(8 + k) * 64 + lane];
 	}
 	const float *h = hrir + ((size_t)dir * 2 + ear) * taps;
 	float2 v[8];
@@ -1026,7 +1057,7 @@ __global__ __launch_bounds__(64) void k_hrtf_table(const float *__restrict__ hri
 
 // The chain [EARLY_REFLECTIONS] alone: stereo out, lane = frame, wave = source.
 template <int FQ>
-__global__ __launch_bounds__(WAVES * 64) void k_er_only(gas_group_args g, gas_dev_state st, uint32_t spw, uint32_t er_R, float *__restrict__ partials, uint32_t p_offset, gas_audio_frame *__restrict__ rows_out) {
+__global__ __launch_bounds__(WAVES * 64) void k_er_only(gas_group_args g, gas_dev_state st, uint32_t er_R, float *__restrict__ partials, uint32_t p_offset, gas_audio_frame *__restrict__ rows_out) {
 	constexpr uint32_t F = FQ * 64;
 	__shared__ float red_all[WAVES * F * 2];
 	const int lane = threadIdx.x & 63;
@@ -1037,8 +1068,8 @@ __global__ __launch_bounds__(WAVES * 64) void k_er_only(gas_group_args g, gas_de
 		accL[t] = 0.0f;
 		accR[t] = 0.0f;
 	}
-	const uint32_t first = (blockIdx.x * WAVES + wave) * spw;
-	const uint32_t last = first + spw < g.n ? first + spw : g.n;
+	uint32_t first, last;
+	wave_range(g.n, blockIdx.x * WAVES + wave, gridDim.x * WAVES, first, last);
 	for (uint32_t e = first; e < last; e++) {
 		const uint32_t slot = g.slots[e];
 		const uint32_t row = g.rows ? g.rows[e] : e;
@@ -1111,9 +1142,9 @@ void gas_make_twiddles(float2 *host_tw) {
 		const int hi = l >> 3, lo = l & 7;
 		for (int k = 0; k < 8; k++) {
 			double a1 = -two_pi * (double)(hi * k) / 64.0;
-			host_tw[l * 16 + k] = make_float2((float)cos(a1), (float)sin(a1));
+			host_tw[k * 64 + l] = make_float2((float)cos(a1), (float)sin(a1)); // [k][lane]: a wave's load of one k is one 512-byte run
 			double a2 = -two_pi * (double)(lo * (hi + 8 * k)) / 512.0;
-			host_tw[l * 16 + 8 + k] = make_float2((float)cos(a2), (float)sin(a2));
+			host_tw[(8 + k) * 64 + l] = make_float2((float)cos(a2), (float)sin(a2));
 		}
 	}
 }
@@ -1123,33 +1154,33 @@ void gas_make_twiddles(float2 *host_tw) {
 // budget (an exact-peak source costs about twice a frequency-domain one) so the whole grid drains in one
 // even round.  At most 64 sources per wave (one metadata lane per source); beyond that the grid grows.
 void gas_hrtf_plan(uint32_t n_fd, uint32_t n_pk, gas_hrtf_launch_plan *p) {
+	// One residency round: 256 CUs x 1 workgroup of WAVES waves.  A group gets as many workgroups as it has
+	// sources / WAVES, capped by its share of the round (exact-peak sources cost two more FFTs each: weight 2) and
+	// raised beyond the round only when a wave would otherwise own more than 64 sources.  Sources are split evenly
+	// over the group's waves (wave_range).
 	const uint32_t budget = 256u * 4u * GAS_HRTF_WAVES_PER_SIMD / WAVES;
-	auto spw_for = [](uint32_t n, uint32_t wgs) {
-		const uint32_t spw = (n + wgs * WAVES - 1) / (wgs * WAVES);
-		return spw < 1 ? 1u : (spw > 64 ? 64u : spw);
+	auto wgs_for = [](uint32_t n, uint32_t cap) {
+		const uint32_t want = (n + WAVES - 1) / WAVES; // one source per wave at least
+		const uint32_t need = (n + WAVES * 64 - 1) / (WAVES * 64); // 64 sources per wave at most
+		const uint32_t w = want < cap ? want : cap;
+		return w > need ? w : need;
 	};
-	p->spw_fd = p->spw_pk = 1;
 	p->wgs_fd = p->wgs_pk = 0;
 	uint32_t budget_fd = budget;
 	if (n_pk) {
 		uint32_t share = n_fd ? (uint32_t)(((uint64_t)budget * 2 * n_pk + (n_fd + 2ull * n_pk) - 1) / (n_fd + 2ull * n_pk)) : budget;
 		share = share < 1 ? 1 : (share > budget - (n_fd ? 1 : 0) ? budget - (n_fd ? 1 : 0) : share);
-		p->spw_pk = spw_for(n_pk, share);
-		p->wgs_pk = (n_pk + p->spw_pk * WAVES - 1) / (p->spw_pk * WAVES);
+		p->wgs_pk = wgs_for(n_pk, share);
 		budget_fd = budget > p->wgs_pk ? budget - p->wgs_pk : 1;
 	}
 	if (n_fd) {
-		p->spw_fd = spw_for(n_fd, budget_fd);
-		p->wgs_fd = (n_fd + p->spw_fd * WAVES - 1) / (p->spw_fd * WAVES);
+		p->wgs_fd = wgs_for(n_fd, budget_fd);
 	}
 }
 
-uint32_t gas_hrtf_partials(uint32_t n, uint32_t *sources_per_wave) {
+uint32_t gas_hrtf_partials(uint32_t n) {
 	gas_hrtf_launch_plan p;
 	gas_hrtf_plan(n, 0, &p);
-	if (sources_per_wave) {
-		*sources_per_wave = p.spw_fd;
-	}
 	return p.wgs_fd;
 }
 
@@ -1162,10 +1193,10 @@ hipError_t gas_launch_hrtf_ols(hipStream_t stream, bool with_er, bool crossfade,
 	}
 	gas_hrtf_launch_plan plan;
 	gas_hrtf_plan(g_fd.n, g_pk.n, &plan);
-	const uint32_t wgs_fd = plan.wgs_fd, spw_fd = plan.spw_fd, spw_pk = plan.spw_pk;
+	const uint32_t wgs_fd = plan.wgs_fd;
 	dim3 grid(plan.wgs_fd + plan.wgs_pk), block(WAVES * 64);
 #define GAS_HRTF_LAUNCH2(SQv, ERv, PCMv, XFv, RNv) \
-	hipLaunchKernelGGL((k_hrtf_ols<SQv, ERv, PCMv, XFv, RNv>), grid, block, 0, stream, g_fd, g_pk, wgs_fd, st, tab, twiddles, spw_fd, spw_pk, er_ring_frames, partials, p_offset, cursors, fade_env, fresh, job)
+	hipLaunchKernelGGL((k_hrtf_ols<SQv, ERv, PCMv, XFv, RNv>), grid, block, 0, stream, g_fd, g_pk, wgs_fd, st, tab, twiddles, er_ring_frames, partials, p_offset, cursors, fade_env, fresh, job)
 #define GAS_HRTF_LAUNCH(SQv, ERv, PCMv, XFv)          \
 	if (runs && !XFv) {                               \
 		GAS_HRTF_LAUNCH2(SQv, ERv, PCMv, false, true); \
@@ -1208,21 +1239,20 @@ hipError_t gas_launch_er_only(hipStream_t stream, const gas_group_args &g, const
 	if (g.n == 0) {
 		return hipSuccess;
 	}
-	uint32_t spw = 1;
-	const uint32_t wgs = gas_hrtf_partials(g.n, &spw);
+	const uint32_t wgs = gas_hrtf_partials(g.n);
 	dim3 grid(wgs), block(WAVES * 64);
 	switch (frames / 64) {
 		case 2:
-			hipLaunchKernelGGL((k_er_only<2>), grid, block, 0, stream, g, st, spw, er_ring_frames, partials, p_offset, rows_out);
+			hipLaunchKernelGGL((k_er_only<2>), grid, block, 0, stream, g, st, er_ring_frames, partials, p_offset, rows_out);
 			break;
 		case 4:
-			hipLaunchKernelGGL((k_er_only<4>), grid, block, 0, stream, g, st, spw, er_ring_frames, partials, p_offset, rows_out);
+			hipLaunchKernelGGL((k_er_only<4>), grid, block, 0, stream, g, st, er_ring_frames, partials, p_offset, rows_out);
 			break;
 		case 6:
-			hipLaunchKernelGGL((k_er_only<6>), grid, block, 0, stream, g, st, spw, er_ring_frames, partials, p_offset, rows_out);
+			hipLaunchKernelGGL((k_er_only<6>), grid, block, 0, stream, g, st, er_ring_frames, partials, p_offset, rows_out);
 			break;
 		case 8:
-			hipLaunchKernelGGL((k_er_only<8>), grid, block, 0, stream, g, st, spw, er_ring_frames, partials, p_offset, rows_out);
+			hipLaunchKernelGGL((k_er_only<8>), grid, block, 0, stream, g, st, er_ring_frames, partials, p_offset, rows_out);
 			break;
 		default:
 			return hipErrorInvalidValue;
@@ -1234,15 +1264,14 @@ hipError_t gas_launch_hrtf_rows(hipStream_t stream, bool crossfade, const gas_gr
 	if (g.n == 0) {
 		return hipSuccess;
 	}
-	uint32_t spw = 1;
-	const uint32_t wgs = gas_hrtf_partials(g.n, &spw);
+	const uint32_t wgs = gas_hrtf_partials(g.n);
 	dim3 grid(wgs), block(WAVES * 64);
 #define GAS_ROWS_CASE(SQv)                                                                                              \
 	case SQv:                                                                                                           \
 		if (crossfade) {                                                                                                \
-			hipLaunchKernelGGL((k_hrtf_rows<SQv, true>), grid, block, 0, stream, g, st, tab, twiddles, spw, rows_out);  \
+			hipLaunchKernelGGL((k_hrtf_rows<SQv, true>), grid, block, 0, stream, g, st, tab, twiddles, rows_out);  \
 		} else {                                                                                                        \
-			hipLaunchKernelGGL((k_hrtf_rows<SQv, false>), grid, block, 0, stream, g, st, tab, twiddles, spw, rows_out); \
+			hipLaunchKernelGGL((k_hrtf_rows<SQv, false>), grid, block, 0, stream, g, st, tab, twiddles, rows_out); \
 		}                                                                                                               \
 		break;
 	switch (frames / 128) {
@@ -1261,21 +1290,20 @@ hipError_t gas_launch_rows_accumulate(hipStream_t stream, const gas_group_args &
 	if (g.n == 0) {
 		return hipSuccess;
 	}
-	uint32_t spw = 1;
-	const uint32_t wgs = gas_hrtf_partials(g.n, &spw);
+	const uint32_t wgs = gas_hrtf_partials(g.n);
 	dim3 grid(wgs), block(WAVES * 64);
 	switch (frames / 64) {
 		case 2:
-			hipLaunchKernelGGL((k_rows_accumulate<2>), grid, block, 0, stream, g, spw, partials, p_offset);
+			hipLaunchKernelGGL((k_rows_accumulate<2>), grid, block, 0, stream, g, partials, p_offset);
 			break;
 		case 4:
-			hipLaunchKernelGGL((k_rows_accumulate<4>), grid, block, 0, stream, g, spw, partials, p_offset);
+			hipLaunchKernelGGL((k_rows_accumulate<4>), grid, block, 0, stream, g, partials, p_offset);
 			break;
 		case 6:
-			hipLaunchKernelGGL((k_rows_accumulate<6>), grid, block, 0, stream, g, spw, partials, p_offset);
+			hipLaunchKernelGGL((k_rows_accumulate<6>), grid, block, 0, stream, g, partials, p_offset);
 			break;
 		case 8:
-			hipLaunchKernelGGL((k_rows_accumulate<8>), grid, block, 0, stream, g, spw, partials, p_offset);
+			hipLaunchKernelGGL((k_rows_accumulate<8>), grid, block, 0, stream, g, partials, p_offset);
 			break;
 		default:
 			return hipErrorInvalidValue;
