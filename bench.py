@@ -132,6 +132,7 @@ def main():
     ap.add_argument("--no-pipelined-mix", action="store_true", help="without GAS_FLAG_PIPELINED_MIX: the partial-mix sum of callback t runs before callback t+1's DSP kernel instead of under it")
     ap.add_argument("--direction-order", action="store_true", help="GAS_FLAG_DIRECTION_ORDER: let the library group sources by HRIR direction (device sort per publish)")
     ap.add_argument("--presorted-directions", action="store_true", help="GAS_FLAG_DIRECTION_RUNS with parameters whose HRIR directions are grouped in callback order (what a caller that sorts its list gets)")
+    ap.add_argument("--draining-every", type=int, default=64, help="1 source in N has ended its stream (exact peak needed, audio_spatializer.cpp:464-469); 0 = none")
     ap.add_argument("--exact-peaks", action="store_true", help="per-source inverse FFTs for every source (exact peak of every source)")
     args = ap.parse_args()
 
@@ -188,7 +189,7 @@ def main():
     slots = ctx.source_alloc_many(n_local, kind, chain)
     n_draining = 0
     if kind == 2:
-        for s_ in slots[::64]:
+        for s_ in (slots[:: args.draining_every] if args.draining_every > 0 else []):
             ctx.source_set_draining(int(s_), True)
             n_draining += 1
 

@@ -52,7 +52,7 @@ __device__ __forceinline__ float2 cmulc(float2 a, float2 b) { // a * conj(b)
 // Once-touched streams (source rows, history) bypass the caches' retention so they do not evict the HRIR
 // spectra table, which is the only data re-read across sources (MI355X_MICROARCH.md nt-weights row).
 #ifndef GAS_ABL
-#define GAS_ABL 0 // timing experiments only (results are wrong): 1 no table loads, 2 no history traffic, 4 no forward FFT, 8 no row loads, 16 no twiddle loads, 32 no frequency-domain epilogue, 64 no per-source state writes
+#define GAS_ABL 0 // timing experiments only (results are wrong): 1 no table loads, 2 no history traffic, 4 no forward FFT, 8 no row loads, 16 no twiddle loads, 32 no frequency-domain epilogue, 64 no per-source state writes, 128 no parameter loads, 256 empty body (the launch's own floor)
 #endif
 #ifdef GAS_USE_NT // measured: no effect on MI355X for this kernel (profiles/r01_notes.md); kept as a switch
 #define GAS_NT_LOAD(p) __builtin_nontemporal_load(p)
@@ -438,6 +438,51 @@ __device__ __forceinline__ void wave_range(uint32_t n, uint32_t gw, uint32_t n_w
 	last = first + base + (gw < rem ? 1u : 0u);
 }
 
+// History rows are stored lane-major -- element lane * HQ + q holds x[lane + 64 q] -- so a lane's HQ samples are one
+// contiguous 4*HQ-byte piece (one 16-byte access at F = 512 instead of four 4-byte ones: the history cost 3.1 us of
+// the 16.7 us kernel as 4-byte accesses).  The layout is private to this file; k_zero_slot only writes zeros.
+template <int HQ>
+__device__ __forceinline__ void load_history(const float *__restrict__ row, int lane, float (&h)[HQ]) {
+	if constexpr (HQ % 4 == 0) {
+#pragma unroll
+		for (int q = 0; q < HQ; q += 4) {
+			const float4 v = *reinterpret_cast<const float4 *>(row + lane * HQ + q);
+			h[q] = v.x; h[q + 1] = v.y; h[q + 2] = v.z; h[q + 3] = v.w;
+		}
+	} else if constexpr (HQ % 2 == 0) {
+#pragma unroll
+		for (int q = 0; q < HQ; q += 2) {
+			const float2 v = *reinterpret_cast<const float2 *>(row + lane * HQ + q);
+			h[q] = v.x; h[q + 1] = v.y;
+		}
+	} else {
+#pragma unroll
+		for (int q = 0; q < HQ; q++) {
+			h[q] = row[lane * HQ + q];
+		}
+	}
+}
+
+template <int HQ>
+__device__ __forceinline__ void store_history(float *__restrict__ row, int lane, const float *h) {
+	if constexpr (HQ % 4 == 0) {
+#pragma unroll
+		for (int q = 0; q < HQ; q += 4) {
+			*reinterpret_cast<float4 *>(row + lane * HQ + q) = make_float4(h[q], h[q + 1], h[q + 2], h[q + 3]);
+		}
+	} else if constexpr (HQ % 2 == 0) {
+#pragma unroll
+		for (int q = 0; q < HQ; q += 2) {
+			*reinterpret_cast<float2 *>(row + lane * HQ + q) = make_float2(h[q], h[q + 1]);
+		}
+	} else {
+#pragma unroll
+		for (int q = 0; q < HQ; q++) {
+			row[lane * HQ + q] = h[q];
+		}
+	}
+}
+
 // SQ = S/64 = F/128: 4 for F = 512, 2 for F = 256.
 //
 // PEAKS = true : every source gets its own pair of inverse FFTs, so its output peak (the input of the
@@ -529,6 +574,17 @@ __device__ __forceinline__ void hrtf_body(float2 *lds_all, const uint32_t wg, co
 	for (int j = 0; j < 8; j++) {
 		zs[j] = make_float2(0.0f, 0.0f);
 	}
+	// SKEW: the spectral products of a transform are taken one transform later.  A source's HRIR row can only be
+	// requested once its direction is known (parameter row -> direction -> table row: two dependent round trips,
+	// 2.7 us of a 16.7 us launch when the first product waited for them), whereas its frames need one; with the skew
+	// the table row of run r travels while run r+1 is loaded and transformed.
+	constexpr bool SKEW = !PEAKS && !XFADE;
+	float2 zp[8]; // spectrum of the previous run, its table row in flight
+	bool have_prev = false; // wave-uniform
+#pragma unroll
+	for (int j = 0; j < 8; j++) {
+		zp[j] = make_float2(0.0f, 0.0f);
+	}
 
 	uint32_t first, last;
 	wave_range(g.n, wg * WAVES + wave, n_wgs * WAVES, first, last);
@@ -555,7 +611,7 @@ __device__ __forceinline__ void hrtf_body(float2 *lds_all, const uint32_t wg, co
 		// `fresh`: parameter rows published from device memory for exactly this callback's list (row order) and not
 		// yet scattered: consume them here and write them through to the slot table (saves the scatter launch).
 		const gas_params *P = fresh ? fresh + lm.row : st.params + lm.slot;
-		if (fresh) {
+		if (fresh && !(GAS_ABL & 128)) {
 			const float4 *src4 = reinterpret_cast<const float4 *>(P);
 			float4 *dst4 = reinterpret_cast<float4 *>(st.params + lm.slot);
 #pragma unroll
@@ -563,8 +619,8 @@ __device__ __forceinline__ void hrtf_body(float2 *lds_all, const uint32_t wg, co
 				dst4[k] = src4[k];
 			}
 		}
-		const float2 gd = *reinterpret_cast<const float2 *>(&P->hrtf_gain); // hrtf_gain, hrtf_dir: one 8-byte load
-		lm.g0 = st.hrtf_prev_gain[lm.slot];
+		const float2 gd = (GAS_ABL & 128) ? make_float2(1.0f, __uint_as_float(lm.slot & 1023u)) : *reinterpret_cast<const float2 *>(&P->hrtf_gain); // hrtf_gain, hrtf_dir: one 8-byte load
+		lm.g0 = (GAS_ABL & 128) ? 0.5f : st.hrtf_prev_gain[lm.slot];
 		lm.g1 = gd.x;
 		const uint32_t d = __float_as_uint(gd.y);
 		lm.dir = d < tab.dirs ? d : 0;
@@ -584,9 +640,8 @@ __device__ __forceinline__ void hrtf_body(float2 *lds_all, const uint32_t wg, co
 				SrcMeta ms{};
 				ms.slot = (uint32_t)__builtin_amdgcn_readlane((int)lm.slot, s);
 				ms.row = (uint32_t)__builtin_amdgcn_readlane((int)lm.row, s);
-#pragma unroll
-				for (int q = 0; q < HQ; q++) {
-					rawh[s][q] = (GAS_ABL & 2) ? (float)lane : GAS_NT_LOAD(&st.hrtf_hist[(size_t)ms.slot * HL + lane + 64 * q]);
+				if (!(GAS_ABL & 2)) {
+					load_history<HQ>(st.hrtf_hist + (size_t)ms.slot * HL, lane, rawh[s]);
 				}
 				if constexpr (!WITH_ER && !SRC_PCM) {
 					load_window<false, FQ>(g, ms, lane, fade_env, raw[s]); // needs the row only
@@ -601,7 +656,9 @@ __device__ __forceinline__ void hrtf_body(float2 *lds_all, const uint32_t wg, co
 				}
 			}
 		}
-		issue_spectra(tab.spec, (uint32_t)__builtin_amdgcn_readlane((int)lm.dir, 0), lane, hs);
+		if constexpr (!SKEW) {
+			issue_spectra(tab.spec, (uint32_t)__builtin_amdgcn_readlane((int)lm.dir, 0), lane, hs);
+		}
 	}
 
 	// STAGES sources per trip, each with its own landing registers: while source e transforms, the frames and
@@ -673,11 +730,8 @@ __device__ __forceinline__ void hrtf_body(float2 *lds_all, const uint32_t wg, co
 			}
 		}
 		// new history = x_full[F .. F + HL)
-#pragma unroll
-		for (int q = 0; q < HQ; q++) {
-			if (!(GAS_ABL & 2)) {
-				GAS_NT_STORE(xq[FQ + q], &st.hrtf_hist[(size_t)m.slot * HL + lane + 64 * q]);
-			}
+		if (!(GAS_ABL & 2)) {
+			store_history<HQ>(st.hrtf_hist + (size_t)m.slot * HL, lane, &xq[FQ]);
 		}
 		if (lane == 0 && !(GAS_ABL & 64)) {
 			st.hrtf_prev_gain[m.slot] = m.g1;
@@ -695,9 +749,8 @@ __device__ __forceinline__ void hrtf_body(float2 *lds_all, const uint32_t wg, co
 		}
 		// this stage's landing registers are free again: start the frames and history of source e + STAGES
 		if (has_ahead) {
-#pragma unroll
-			for (int q = 0; q < HQ; q++) {
-				rawh[s][q] = (GAS_ABL & 2) ? (float)lane : GAS_NT_LOAD(&st.hrtf_hist[(size_t)ma.slot * HL + lane + 64 * q]);
+			if (!(GAS_ABL & 2)) {
+				load_history<HQ>(st.hrtf_hist + (size_t)ma.slot * HL, lane, rawh[s]);
 			}
 			if constexpr (!WITH_ER) {
 				load_window<SRC_PCM, FQ>(g, ma, lane, fade_env, raw[s]);
@@ -793,6 +846,23 @@ __device__ __forceinline__ void hrtf_body(float2 *lds_all, const uint32_t wg, co
 				if (!(GAS_ABL & 4)) {
 					fft512<false>(zs, t1, t2, lds, lane);
 				}
+				if constexpr (SKEW) {
+					if (have_prev) {
+						finish_spectra(lane, hs);
+#pragma unroll
+						for (int j = 0; j < 8; j++) {
+							aYL[j] = cadd(aYL[j], cmul(zp[j], make_float2(hs[j].x, hs[j].y)));
+							aYR[j] = cadd(aYR[j], cmul(zp[j], make_float2(hs[j].z, hs[j].w)));
+						}
+					}
+					issue_spectra(tab.spec, m.dir, lane, hs); // this run's row: consumed after the next transform
+#pragma unroll
+					for (int j = 0; j < 8; j++) {
+						zp[j] = zs[j];
+						zs[j] = make_float2(0.0f, 0.0f);
+					}
+					have_prev = true;
+				} else {
 				finish_spectra(lane, hs);
 #pragma unroll
 				for (int j = 0; j < 8; j++) {
@@ -825,6 +895,7 @@ __device__ __forceinline__ void hrtf_body(float2 *lds_all, const uint32_t wg, co
 				if (has_next) {
 					issue_spectra(tab.spec, mn.dir, lane, hs);
 				}
+				}
 			}
 			if (lane == 0 && !(GAS_ABL & 64)) {
 				g.peaks[(size_t)m.row * 2] = __builtin_inff();
@@ -834,6 +905,16 @@ __device__ __forceinline__ void hrtf_body(float2 *lds_all, const uint32_t wg, co
 		}
 	}
 
+	if constexpr (SKEW) {
+		if (have_prev) { // the last run's products
+			finish_spectra(lane, hs);
+#pragma unroll
+			for (int j = 0; j < 8; j++) {
+				aYL[j] = cadd(aYL[j], cmul(zp[j], make_float2(hs[j].x, hs[j].y)));
+				aYR[j] = cadd(aYR[j], cmul(zp[j], make_float2(hs[j].z, hs[j].w)));
+			}
+		}
+	}
 	if (PEAKS && rows_out) {
 		return; // rows-out stage: nothing to sum here (wave-uniform for the whole launch)
 	}
@@ -943,6 +1024,8 @@ __device__ __forceinline__ void hrtf_body(float2 *lds_all, const uint32_t wg, co
 	(void)bYL;
 	(void)bYR;
 	(void)zs;
+	(void)zp;
+	(void)have_prev;
 	(void)jr;
 	(void)job_mine;
 }
@@ -954,6 +1037,9 @@ __global__ __launch_bounds__(WAVES * 64, GAS_HRTF_WAVES_PER_SIMD) void k_hrtf_ol
 	constexpr int LDS_F2 = HrtfLds<SQ, false>::TOTAL_F2 > HrtfLds<SQ, true>::TOTAL_F2 ? HrtfLds<SQ, false>::TOTAL_F2 : HrtfLds<SQ, true>::TOTAL_F2;
 	__shared__ float2 lds_all[LDS_F2];
 	__shared__ float4 job_red[GAS_HRTF_JOB_WAVES * 64];
+	if ((GAS_ABL & 256) && wgs_fd != 0xffffffffu) {
+		return;
+	}
 	float *my_partial = partials + ((size_t)p_offset + blockIdx.x) * (size_t)(2 * SQ * 64 * 2);
 	if (blockIdx.x < wgs_fd) {
 		hrtf_body<SQ, WITH_ER, false, SRC_PCM, XFADE, RUNS>(lds_all, blockIdx.x, g_fd, st, tab, tw, wgs_fd, er_R, my_partial, cursors, fade_env, fresh, nullptr, job, job_red, blockIdx.x, gridDim.x);
@@ -1153,6 +1239,9 @@ void gas_make_twiddles(float2 *host_tw) {
 // 256 * 4 * that / WAVES workgroups at a time; the frequency-domain and exact-peak workgroups share that
 // budget (an exact-peak source costs about twice a frequency-domain one) so the whole grid drains in one
 // even round.  At most 64 sources per wave (one metadata lane per source); beyond that the grid grows.
+#ifndef GAS_PK_WEIGHT
+#define GAS_PK_WEIGHT 2
+#endif
 void gas_hrtf_plan(uint32_t n_fd, uint32_t n_pk, gas_hrtf_launch_plan *p) {
 	// One residency round: 256 CUs x 1 workgroup of WAVES waves.  A group gets as many workgroups as it has
 	// sources / WAVES, capped by its share of the round (exact-peak sources cost two more FFTs each: weight 2) and
@@ -1168,7 +1257,7 @@ void gas_hrtf_plan(uint32_t n_fd, uint32_t n_pk, gas_hrtf_launch_plan *p) {
 	p->wgs_fd = p->wgs_pk = 0;
 	uint32_t budget_fd = budget;
 	if (n_pk) {
-		uint32_t share = n_fd ? (uint32_t)(((uint64_t)budget * 2 * n_pk + (n_fd + 2ull * n_pk) - 1) / (n_fd + 2ull * n_pk)) : budget;
+		uint32_t share = n_fd ? (uint32_t)(((uint64_t)budget * GAS_PK_WEIGHT * n_pk + (n_fd + (uint64_t)GAS_PK_WEIGHT * n_pk) - 1) / (n_fd + (uint64_t)GAS_PK_WEIGHT * n_pk)) : budget;
 		share = share < 1 ? 1 : (share > budget - (n_fd ? 1 : 0) ? budget - (n_fd ? 1 : 0) : share);
 		p->wgs_pk = wgs_for(n_pk, share);
 		budget_fd = budget > p->wgs_pk ? budget - p->wgs_pk : 1;
