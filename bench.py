@@ -233,6 +233,8 @@ def main():
     out_ptr = [[buckets[b][i].data_ptr() for i in range(B)] for b in range(2)]
     peaks_ptr = peaks.data_ptr()
 
+    pipelined = not args.no_pipelined_mix
+
     def step(k):
         if k % 2 == 0:
             ctx.params_publish_device(pset_ptr[(k // 2) % 2], n_local)
@@ -243,17 +245,21 @@ def main():
         rc = ctx.process_block_raw(src_ptr[k % n_bufs], None, n_local, frames, out_ptr[b][i], peaks_ptr, gas.capi.MEM_DEVICE)
         if rc != 0:
             raise SystemExit(f"gas_process_block failed: {rc}")
-        if i == B - 1:
-            ctx.join_outputs()  # the bucket's B mixes, written on the library's reduce stream, before it is consumed
+        if pipelined:
+            # the last mix of the previous bucket rode in the launch above: that bucket is complete in stream order now
+            if i == 0 and k > 0:
+                pending[1 - b] = reducer.reduce(buckets[1 - b])
+        elif i == B - 1:
             pending[b] = reducer.reduce(buckets[b])
 
     def drain(k_end):
-        if k_end % B != 0:  # a partly filled bucket still has to reach rank 0
-            b = (k_end // B) % 2
+        # the bucket holding the last callback still has to reach rank 0: always in pipelined mode (its reduce is
+        # issued one callback late), else only when it is partly filled
+        if k_end > 0 and (pipelined or k_end % B != 0):
+            b = ((k_end - 1) // B) % 2
             reducer.wait(pending[b])
-            ctx.join_outputs()
+            ctx.join_outputs()  # enqueue the pending sum of the last callback
             pending[b] = reducer.reduce(buckets[b])
-        ctx.join_outputs()
         for i in range(2):
             reducer.wait(pending[i])
             pending[i] = None
