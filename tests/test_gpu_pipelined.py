@@ -43,11 +43,15 @@ def _render(gas, flags, kind, chain, n, F, T, channel_count=1, host_call_at=None
     return res.cpu().numpy(), pk.cpu().numpy()
 
 
-@pytest.mark.parametrize("case", ["hrtf", "mix_channel_4", "hrtf_with_host_call"])
+@pytest.mark.parametrize("case", ["hrtf", "mix_channel_4", "hrtf_with_host_call", "hrtf_f256", "hrtf_f128", "hrtf_f384", "hrtf_small_grid"])
 def test_pipelined_mix_is_bitwise_identical(gas, case):
     K = gas.capi
     if case == "mix_channel_4":
         args = dict(kind=K.KIND_3D_MIX, chain=(), n=300, F=512, T=9, channel_count=4)
+    elif case.startswith("hrtf_f"):  # other frame counts: other column -> workgroup maps of the carried sum
+        args = dict(kind=K.KIND_EFFECT, chain=(K.FX_HRTF,), n=900, F=int(case[6:]), T=7)
+    elif case == "hrtf_small_grid":  # too few workgroups to carry a sum: summed immediately
+        args = dict(kind=K.KIND_EFFECT, chain=(K.FX_HRTF,), n=40, F=512, T=6)
     else:
         args = dict(kind=K.KIND_EFFECT, chain=(K.FX_HRTF,), n=700, F=512, T=10, host_call_at=4 if case.endswith("host_call") else None)
     base, pk0 = _render(gas, K.FLAG_PEAKS_DRAINING_ONLY, **args)
