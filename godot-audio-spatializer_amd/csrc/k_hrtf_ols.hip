@@ -25,6 +25,7 @@
 //
 // Bound: HBM.  Algorithmic bytes/source = F*8 (source) + 2*hist_len*4 (history r+w) + 128 (params) + 8
 // (peak) + 8 (gain state), + the ring traffic (8 taps * F * 8 read + F * 8 write) with early reflections.
+#include "gas_device.h"
 #include "gas_internal.h"
 
 namespace {
@@ -395,9 +396,9 @@ __device__ __forceinline__ void finish_spectra(int lane, float4 (&hs)[8]) {
 
 // The previous callback's k_mix_reduce, done by one wave of this workgroup for float4 column `col` (one column per
 // job wave; the context only hands a job over when the grid covers every column and p_count <= 256).  The four
-// partial rows a lane sums are loaded at kernel start and parked in registers, so the sum itself -- the same
-// operations in the same order as k_mix_reduce with lane = its `prow`, hence the same bits -- finds them landed
-// and hides behind the other waves' epilogue.
+// partial rows a lane sums are loaded at kernel start and parked in registers, so the sum itself -- gas_device.h's
+// column sum, the very code k_mix_reduce runs, hence the same bits -- finds them landed and hides behind the other
+// waves' epilogue.
 constexpr int JOB_ROWS = 4; // rows lane, lane + 64, lane + 128, lane + 192
 __device__ __forceinline__ void job_issue(const gas_deferred_reduce &j, uint32_t col, int lane, float4 (&jr)[JOB_ROWS]) {
 	const uint32_t e4 = j.elems / 4;
@@ -411,27 +412,20 @@ __device__ __forceinline__ void job_issue(const gas_deferred_reduce &j, uint32_t
 	}
 }
 
-__device__ __forceinline__ void job_finish(const gas_deferred_reduce &j, uint32_t col, int lane, const float4 (&jr)[JOB_ROWS], float4 *red) {
+__device__ __forceinline__ void job_finish(const gas_deferred_reduce &j, uint32_t col, int lane, const float4 (&jr)[JOB_ROWS]) {
 	float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
 	for (int r = 0; r < JOB_ROWS; r++) {
-		s.x += jr[r].x; s.y += jr[r].y; s.z += jr[r].z; s.w += jr[r].w;
+		gas_mix_column_add(s, jr[r]);
 	}
-	red[lane] = s;
-	wave_lds_sync();
+	const float4 t = gas_mix_column_fold(s);
 	if (lane == 0) {
-		float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll 8
-		for (int q = 0; q < 64; q++) {
-			const float4 a = red[q];
-			t.x += a.x; t.y += a.y; t.z += a.z; t.w += a.w;
-		}
 		reinterpret_cast<float4 *>(j.out)[col] = t;
 	}
 }
 
 // Sources [first, last) of wave `gw` out of `n_waves`: an even split (the first n % n_waves waves take one more), so
-// every planned workgroup has work -- a uniform ceil(n / n_waves) per wave left 21 % of the CUs idle at 8064 sources.
+// every planned workgroup has work.
 __device__ __forceinline__ void wave_range(uint32_t n, uint32_t gw, uint32_t n_waves, uint32_t &first, uint32_t &last) {
 	const uint32_t base = n / n_waves, rem = n % n_waves;
 	first = gw * base + (gw < rem ? gw : rem);
@@ -505,7 +499,7 @@ struct HrtfLds {
 };
 
 template <int SQ, bool WITH_ER, bool PEAKS, bool SRC_PCM, bool XFADE, bool RUNS = false>
-__device__ __forceinline__ void hrtf_body(float2 *lds_all, const uint32_t wg, const gas_group_args &g, const gas_dev_state &st, const gas_hrtf_table &tab, const float2 *__restrict__ tw, uint32_t n_wgs, uint32_t er_R, float *__restrict__ my_partial, gas_cursor *__restrict__ cursors, const float *__restrict__ fade_env, const gas_params *__restrict__ fresh, gas_audio_frame *__restrict__ rows_out = nullptr, const gas_deferred_reduce job = gas_deferred_reduce(), float4 *job_red = nullptr, uint32_t job_col = 0, uint32_t job_nwg = 1) {
+__device__ __forceinline__ void hrtf_body(float2 *lds_all, const uint32_t wg, const gas_group_args &g, const gas_dev_state &st, const gas_hrtf_table &tab, const float2 *__restrict__ tw, uint32_t n_wgs, uint32_t er_R, float *__restrict__ my_partial, gas_cursor *__restrict__ cursors, const float *__restrict__ fade_env, const gas_params *__restrict__ fresh, gas_audio_frame *__restrict__ rows_out = nullptr, const gas_deferred_reduce job = gas_deferred_reduce(), uint32_t job_col = 0) {
 	static_assert(!(WITH_ER && SRC_PCM), "the early-reflection prologue reads float rows");
 	constexpr int FQ = 2 * SQ; // F / 64
 	constexpr int HQ = 8 - SQ; // hist_len / 64
@@ -537,7 +531,6 @@ __device__ __forceinline__ void hrtf_body(float2 *lds_all, const uint32_t wg, co
 		// into one L2 only: job_col holds the workgroup index w; XCD x = w % 8, i = w / 8.
 		const uint32_t jw = (uint32_t)(wave - 2), jx = job_col & 7, ji = job_col >> 3;
 		job_col = (((ji >> 1) * 8 + jx) * 8) + (ji & 1) * 4 + jw;
-		job_red += (jw < GAS_HRTF_JOB_WAVES ? jw : 0) * 64;
 		job_mine = job.partials != nullptr && wave >= 2 && jw < GAS_HRTF_JOB_WAVES && job_col < job.elems / 4; // wave-uniform
 		if (job_mine) {
 			job_issue(job, job_col, lane, jr);
@@ -928,7 +921,7 @@ __device__ __forceinline__ void hrtf_body(float2 *lds_all, const uint32_t wg, co
 		}
 		if constexpr (JOB_OK) {
 			if (job_mine) {
-				job_finish(job, job_col, lane, jr, job_red);
+				job_finish(job, job_col, lane, jr);
 			}
 		}
 		__syncthreads();
@@ -983,7 +976,7 @@ __device__ __forceinline__ void hrtf_body(float2 *lds_all, const uint32_t wg, co
 			__syncthreads();
 			if constexpr (JOB_OK) {
 				if (job_mine && round == 0) { // waves 2.. idle while 0 and 1 transform: the previous callback's sum
-					job_finish(job, job_col, lane, jr, job_red);
+					job_finish(job, job_col, lane, jr);
 				}
 			}
 			if (wave < 2) {
@@ -1036,15 +1029,14 @@ template <int SQ, bool WITH_ER, bool SRC_PCM, bool XFADE, bool RUNS>
 __global__ __launch_bounds__(WAVES * 64, GAS_HRTF_WAVES_PER_SIMD) void k_hrtf_ols(gas_group_args g_fd, gas_group_args g_pk, uint32_t wgs_fd, gas_dev_state st, gas_hrtf_table tab, const float2 *__restrict__ tw, uint32_t er_R, float *__restrict__ partials, uint32_t p_offset, gas_cursor *__restrict__ cursors, const float *__restrict__ fade_env, const gas_params *__restrict__ fresh, gas_deferred_reduce job) {
 	constexpr int LDS_F2 = HrtfLds<SQ, false>::TOTAL_F2 > HrtfLds<SQ, true>::TOTAL_F2 ? HrtfLds<SQ, false>::TOTAL_F2 : HrtfLds<SQ, true>::TOTAL_F2;
 	__shared__ float2 lds_all[LDS_F2];
-	__shared__ float4 job_red[GAS_HRTF_JOB_WAVES * 64];
 	if ((GAS_ABL & 256) && wgs_fd != 0xffffffffu) {
 		return;
 	}
 	float *my_partial = partials + ((size_t)p_offset + blockIdx.x) * (size_t)(2 * SQ * 64 * 2);
 	if (blockIdx.x < wgs_fd) {
-		hrtf_body<SQ, WITH_ER, false, SRC_PCM, XFADE, RUNS>(lds_all, blockIdx.x, g_fd, st, tab, tw, wgs_fd, er_R, my_partial, cursors, fade_env, fresh, nullptr, job, job_red, blockIdx.x, gridDim.x);
+		hrtf_body<SQ, WITH_ER, false, SRC_PCM, XFADE, RUNS>(lds_all, blockIdx.x, g_fd, st, tab, tw, wgs_fd, er_R, my_partial, cursors, fade_env, fresh, nullptr, job, blockIdx.x);
 	} else {
-		hrtf_body<SQ, WITH_ER, true, SRC_PCM, XFADE>(lds_all, blockIdx.x - wgs_fd, g_pk, st, tab, tw, gridDim.x - wgs_fd, er_R, my_partial, cursors, fade_env, fresh, nullptr, job, job_red, blockIdx.x, gridDim.x);
+		hrtf_body<SQ, WITH_ER, true, SRC_PCM, XFADE>(lds_all, blockIdx.x - wgs_fd, g_pk, st, tab, tw, gridDim.x - wgs_fd, er_R, my_partial, cursors, fade_env, fresh, nullptr, job, blockIdx.x);
 	}
 }
 

@@ -5,51 +5,42 @@
 //   k_scatter_params  publish staged SpatializerParameters PODs into the slot-indexed table
 //                     (set_spatializer_parameters, audio_spatializer.cpp:558-564)
 //   k_zero_slot       fresh SpatializerPlaybackData for a (re)started playback (audio_spatializer.cpp:69)
+#include "gas_device.h"
 #include "gas_internal.h"
 
 namespace {
 
-constexpr int RED_ROWS = 64; // partial rows summed in parallel per output column
-constexpr int RED_COLS = 4; // float4 columns (16 output floats) per workgroup; 256 threads = 64 x 4
+constexpr int RED_COLS = 4; // float4 columns (16 output floats) per workgroup: one wave each
 
-// out[c][i] = sum_p partials[c][p][i].  Thread (prow, col) adds partial rows prow, prow+64, ... of its float4
-// column (four independent 16-byte loads in flight per trip), then the 64 row sums are added in fixed order.
-// Bitwise reproducible; no atomics.
-__global__ __launch_bounds__(256) void k_mix_reduce(const float *__restrict__ partials, uint32_t p_count, uint32_t p_stride, uint32_t elems /* F*2, multiple of 4 */, float *__restrict__ out) {
-	__shared__ float4 red[RED_ROWS][RED_COLS];
-	const int col = threadIdx.x & (RED_COLS - 1);
-	const int prow = threadIdx.x / RED_COLS;
-	const uint32_t i4 = blockIdx.x * RED_COLS + col; // float4 index within a partial
+// out[c][i] = sum_p partials[c][p][i].  One wave per float4 column; lane l adds partial rows l, l + 64, ... (four
+// independent 16-byte loads in flight per trip), then the 64 lane sums are folded in the fixed order of
+// gas_wave_sum.  Bitwise reproducible; no atomics; no LDS.
+__global__ __launch_bounds__(RED_COLS * 64) void k_mix_reduce(const float *__restrict__ partials, uint32_t p_count, uint32_t p_stride, uint32_t elems /* F*2, multiple of 4 */, float *__restrict__ out) {
+	const int lane = threadIdx.x & 63;
+	const uint32_t i4 = blockIdx.x * RED_COLS + (threadIdx.x >> 6); // float4 index within a partial
 	const uint32_t c = blockIdx.y;
 	const uint32_t e4 = elems / 4;
-	float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-	if (i4 < e4) {
-		const float4 *p = reinterpret_cast<const float4 *>(partials + (size_t)c * p_stride * elems) + i4;
-		uint32_t k = prow;
-		for (; k + 3 * RED_ROWS < p_count; k += 4 * RED_ROWS) {
-			const float4 a0 = p[(size_t)k * e4];
-			const float4 a1 = p[(size_t)(k + RED_ROWS) * e4];
-			const float4 a2 = p[(size_t)(k + 2 * RED_ROWS) * e4];
-			const float4 a3 = p[(size_t)(k + 3 * RED_ROWS) * e4];
-			s.x += a0.x; s.y += a0.y; s.z += a0.z; s.w += a0.w;
-			s.x += a1.x; s.y += a1.y; s.z += a1.z; s.w += a1.w;
-			s.x += a2.x; s.y += a2.y; s.z += a2.z; s.w += a2.w;
-			s.x += a3.x; s.y += a3.y; s.z += a3.z; s.w += a3.w;
-		}
-		for (; k < p_count; k += RED_ROWS) {
-			const float4 a = p[(size_t)k * e4];
-			s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
-		}
+	if (i4 >= e4) { // wave-uniform
+		return;
 	}
-	red[prow][col] = s;
-	__syncthreads();
-	if (prow == 0 && i4 < e4) {
-		float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll 8
-		for (int q = 0; q < RED_ROWS; q++) {
-			const float4 a = red[q][col];
-			t.x += a.x; t.y += a.y; t.z += a.z; t.w += a.w;
-		}
+	float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+	const float4 *p = reinterpret_cast<const float4 *>(partials + (size_t)c * p_stride * elems) + i4;
+	uint32_t k = lane;
+	for (; k + 3 * 64 < p_count; k += 4 * 64) {
+		const float4 a0 = p[(size_t)k * e4];
+		const float4 a1 = p[(size_t)(k + 64) * e4];
+		const float4 a2 = p[(size_t)(k + 128) * e4];
+		const float4 a3 = p[(size_t)(k + 192) * e4];
+		gas_mix_column_add(s, a0);
+		gas_mix_column_add(s, a1);
+		gas_mix_column_add(s, a2);
+		gas_mix_column_add(s, a3);
+	}
+	for (; k < p_count; k += 64) {
+		gas_mix_column_add(s, p[(size_t)k * e4]);
+	}
+	const float4 t = gas_mix_column_fold(s);
+	if (lane == 0) {
 		reinterpret_cast<float4 *>(out + (size_t)c * elems)[i4] = t;
 	}
 }
@@ -238,7 +229,7 @@ hipError_t gas_launch_dir_order(hipStream_t stream, const gas_group_args &g, con
 hipError_t gas_launch_mix_reduce(hipStream_t stream, const float *partials, uint32_t p_count, uint32_t p_stride, uint32_t channels, uint32_t frames, gas_audio_frame *out) {
 	const uint32_t elems = frames * 2;
 	dim3 grid((elems / 4 + RED_COLS - 1) / RED_COLS, channels);
-	hipLaunchKernelGGL(k_mix_reduce, grid, dim3(256), 0, stream, partials, p_count, p_stride, elems, reinterpret_cast<float *>(out));
+	hipLaunchKernelGGL(k_mix_reduce, grid, dim3(RED_COLS * 64), 0, stream, partials, p_count, p_stride, elems, reinterpret_cast<float *>(out));
 	return hipGetLastError();
 }
 
