@@ -1,0 +1,102 @@
+"""A long mixed session through the C ABI against per-playback oracles: playbacks of five different chains come and
+go from callback to callback (the list and its order change, as audio_spatializer.cpp:353-470 walks whatever is
+active), parameters are published for random subsets, some streams end.  State of a playback that sits a callback
+out must be untouched.  A second pass replays the session with device buffers in throughput mode
+(GAS_FLAG_PIPELINED_MIX) and must reproduce the first pass bit for bit."""
+import numpy as np
+import pytest
+
+from helpers import TOL, rel_rms
+
+pytestmark = pytest.mark.gpu
+
+HS, ER, HRTF = 1, 2, 3
+CHAINS = [((HRTF,), 9), ((ER, HRTF), 6), ((HS,), 5), ((HS, HRTF), 5), ((), 3), ((HRTF, HS), 3)]
+F, RING, DIRS, T = 256, 2048, 24, 26
+
+
+def _script(seed):
+    """The session, as data: per callback the active playbacks (in order), who gets new parameters, who drains."""
+    from godot_audio_spatializer_amd import synth
+
+    rng = np.random.default_rng(seed)
+    n = sum(m for _, m in CHAINS)
+    steps = []
+    for t in range(T):
+        k = int(rng.integers(1, n + 1))
+        active = rng.permutation(n)[:k]
+        pub = rng.permutation(n)[: int(rng.integers(0, n + 1))] if t % 2 == 0 or t < 2 else np.zeros(0, np.int64)
+        if t == 0:
+            pub = np.arange(n)
+        params = synth.draw_params(rng, n, dirs=DIRS, ring_frames=RING, frames=F)
+        src = synth.draw_sources(rng, n, F)
+        drain = rng.integers(0, n, 2) if t in (7, 15) else np.zeros(0, np.int64)
+        steps.append((active, pub, params, src, drain))
+    return n, steps
+
+
+def _alloc(gas, ctx):
+    slots = []
+    for ch, m in CHAINS:
+        slots += list(ctx.source_alloc_many(m, gas.capi.KIND_EFFECT, ch))
+    return np.asarray(slots, np.uint32)
+
+
+def test_long_mixed_session_matches_per_playback_oracles(gas, ob):
+    from godot_audio_spatializer_amd import synth
+
+    K = gas.capi
+    hrir = synth.synthetic_hrir(np.random.default_rng(7), dirs=DIRS)
+    n, steps = _script(99)
+    ctx = gas.SpatializerContext(max_sources=n, frames=F, er_ring_frames=RING, flags=K.FLAG_PEAKS_DRAINING_ONLY)
+    ctx.hrtf_load(hrir)
+    slots = _alloc(gas, ctx)
+    chain_of = [ch for ch, m in CHAINS for _ in range(m)]
+    oras = [ob.BatchOracle(ob.KIND_EFFECT, 1, F, chain=ch, hrir=hrir if HRTF in ch else None, er_ring_frames=RING) for ch in chain_of]
+    cur = np.zeros(n, ob.PARAMS_DTYPE)
+    draining = np.zeros(n, bool)
+    outs = []
+    for t, (active, pub, params, src, drain) in enumerate(steps):
+        if len(pub):
+            ctx.params_publish_batch(slots[pub], params[pub])
+            cur[pub] = params[pub].astype(ob.PARAMS_DTYPE)
+        for d in drain:
+            ctx.source_set_draining(slots[d], True)
+            draining[d] = True
+        mix, peaks = ctx.process_block(src[active], slots[active])
+        ref = np.zeros((F, 2))
+        for row, i in enumerate(active):
+            _, pk, m64 = oras[i].block(cur[i : i + 1], src[i : i + 1], want64=True)
+            ref += m64[0]
+            fused_fd = chain_of[i] in ((HRTF,), (ER, HRTF)) and not draining[i]
+            if fused_fd:
+                assert np.all(np.isposinf(peaks[row]))
+            else:
+                np.testing.assert_allclose(peaks[row], pk[0], rtol=3e-5, atol=1e-7)
+        assert rel_rms(mix[0], ref) <= TOL, f"callback {t}"
+        outs.append(mix.copy())
+    ctx.close()
+
+    # the same session, device buffers, throughput mode: bit for bit
+    import torch
+
+    ctx = gas.SpatializerContext(max_sources=n, frames=F, er_ring_frames=RING, flags=K.FLAG_PEAKS_DRAINING_ONLY | K.FLAG_PIPELINED_MIX)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    ctx.hrtf_load(hrir)
+    slots = _alloc(gas, ctx)
+    d_out = torch.zeros(T, 1, F, 2, device="cuda")
+    d_pk = torch.zeros(n, 2, device="cuda")
+    keep = []
+    for t, (active, pub, params, src, drain) in enumerate(steps):
+        if len(pub):
+            ctx.params_publish_batch(slots[pub], params[pub])
+        for d in drain:
+            ctx.source_set_draining(slots[d], True)
+        d_src = torch.from_numpy(np.ascontiguousarray(src[active])).cuda()
+        keep.append(d_src)
+        assert ctx.process_block_raw(d_src.data_ptr(), slots[active], len(active), F, d_out[t].data_ptr(), d_pk.data_ptr(), K.MEM_DEVICE) == 0
+    ctx.synchronize()
+    got = d_out.cpu().numpy()
+    ctx.close()
+    for t in range(T):
+        assert np.array_equal(got[t], outs[t]), f"callback {t}"
