@@ -127,7 +127,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-max-sources", action="store_true")
     ap.add_argument("--profile-every", type=int, default=4, help="bracket the dominant kernel of every Nth step with HIP events (markers cost ~2 us each)")
-    ap.add_argument("--reduce-bucket", type=int, default=8, help="callbacks per cross-GPU reduce (N > 1)")
+    ap.add_argument("--reduce-bucket", type=int, default=32, help="callbacks per cross-GPU reduce (N > 1)")
     ap.add_argument("--crossfade", action="store_true", help="GAS_FLAG_HRTF_CROSSFADE: blend old/new HRIRs when a source's direction changes (SURVEY 8f#4)")
     ap.add_argument("--no-pipelined-mix", action="store_true", help="without GAS_FLAG_PIPELINED_MIX: the partial-mix sum of callback t runs before callback t+1's DSP kernel instead of under it")
     ap.add_argument("--direction-order", action="store_true", help="GAS_FLAG_DIRECTION_ORDER: let the library group sources by HRIR direction (device sort per publish)")
@@ -212,7 +212,7 @@ def main():
     # Partial mixes land in buckets of B callbacks; on N > 1 GPUs each full bucket is sum-reduced to rank 0
     # in ONE collective (B x 4 KiB) on a side stream while the next bucket is being computed: the 4 KiB
     # per-callback message is latency-bound over xGMI, so it is batched instead of sent 40 000 times a second.
-    # Added latency = B callbacks of compute (B * ~25 us), far inside the 10.67 ms real-time budget.
+    # Added latency = B callbacks of compute (32 * ~20 us = 0.65 ms), far inside the 10.67 ms real-time budget.
     B = max(1, args.reduce_bucket)
     buckets = [torch.zeros(B, 1, frames, 2, device="cuda") for _ in range(2)]
     peaks = torch.zeros(n_local, 2, device="cuda")
