@@ -18,7 +18,7 @@ def to_float_stereo(pcm):
     return np.stack([f, f], axis=1) if pcm.ndim == 1 else f
 
 
-@pytest.mark.parametrize("kind_name", ["effect_copy", "mix_channel", "hrtf", "hrtf_crossfade"])
+@pytest.mark.parametrize("kind_name", ["effect_copy", "mix_channel", "hrtf", "hrtf_crossfade", "hrtf_throughput_mode"])
 def test_streams_match_oracle_mixer(gas, ob, kind_name):
     from godot_audio_spatializer_amd import synth
 
@@ -35,10 +35,11 @@ def test_streams_match_oracle_mixer(gas, ob, kind_name):
         "mix_channel": (K.KIND_3D_MIX, ob.KIND_3D_MIX, (), (), None),
         "hrtf": (K.KIND_EFFECT, ob.KIND_EFFECT, (K.FX_HRTF,), (ob.FX_HRTF,), synth.synthetic_hrir(np.random.default_rng(7), dirs=8)),
         "hrtf_crossfade": (K.KIND_EFFECT, ob.KIND_EFFECT, (K.FX_HRTF,), (ob.FX_HRTF,), synth.synthetic_hrir(np.random.default_rng(7), dirs=8)),
+        "hrtf_throughput_mode": (K.KIND_EFFECT, ob.KIND_EFFECT, (K.FX_HRTF,), (ob.FX_HRTF,), synth.synthetic_hrir(np.random.default_rng(7), dirs=8)),
     }[kind_name]
     xf = kind_name == "hrtf_crossfade"
     params = synth.draw_params(rng, n, dirs=8)
-    with gas.SpatializerContext(max_sources=n, frames=F, flags=K.FLAG_PEAKS_DRAINING_ONLY | (K.FLAG_HRTF_CROSSFADE if xf else 0)) as ctx:
+    with gas.SpatializerContext(max_sources=n, frames=F, flags=K.FLAG_PEAKS_DRAINING_ONLY | (K.FLAG_HRTF_CROSSFADE if xf else 0) | (K.FLAG_PIPELINED_MIX if kind_name.endswith("throughput_mode") else 0)) as ctx:
         if hrir is not None:
             ctx.hrtf_load(hrir)
         slots = ctx.source_alloc_many(n, kind, chain)
