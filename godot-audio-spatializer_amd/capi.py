@@ -106,6 +106,7 @@ SPAT3D_CONFIG_DTYPE = np.dtype(
     ]
 )
 POSE_DTYPE = np.dtype([("position", np.float32, (3,)), ("volume_db", np.float32), ("velocity", np.float32, (3,)), ("max_db", np.float32), ("forward", np.float32, (3,)), ("pitch_scale", np.float32)])
+AREA_SEND_DTYPE = np.dtype([("using_reverb_bus", np.uint32), ("reverb_uniformity", np.float32), ("reverb_amount", np.float32), ("present", np.uint32)])
 LISTENER_DTYPE = np.dtype([("basis", np.float32, (3, 3)), ("origin", np.float32, (3,)), ("velocity", np.float32, (3,)), ("pad", np.float32)])
 assert SPAT3D_CONFIG_DTYPE.itemsize == 64 and POSE_DTYPE.itemsize == 48 and LISTENER_DTYPE.itemsize == 64
 
@@ -145,6 +146,7 @@ EXPORTS = [
     "gas_params_publish_batch",
     "gas_hrtf_load",
     "gas_calc_spatialization",
+    "gas_calc_spatialization_areas",
     "gas_stream_create",
     "gas_stream_destroy",
     "gas_source_bind_stream",
@@ -217,6 +219,7 @@ def load_library():
     L.gas_source_bind_stream.argtypes = [vp, u32, u32, C.c_uint64]
     L.gas_process_block_streams.argtypes = [vp, vp, u32, u32, vp, vp, vp, i32]
     L.gas_calc_spatialization.argtypes = [vp, vp, u32, vp, vp, vp, u32, vp, u32, vp, i32]
+    L.gas_calc_spatialization_areas.argtypes = [vp, vp, u32, vp, vp, vp, u32, vp, u32, vp, vp, vp, vp, i32]
     L.gas_process_block.argtypes = [vp, vp, vp, u32, u32, vp, vp, i32]
     L.gas_process_frames_1.argtypes = [vp, u32, vp, vp, i32]
     L.gas_mix_channel_1.argtypes = [vp, u32, i32, vp, vp, i32]
@@ -317,6 +320,23 @@ class SpatializerContext:
         rc = self.lib.gas_calc_spatialization(self.h, _np_ptr(cfgs), len(cfgs), _np_ptr(ci) if ci is not None else None, _np_ptr(poses), _np_ptr(listeners), len(listeners), _np_ptr(slots), len(slots), _np_ptr(out) if want_params else None, MEM_HOST)
         self._check(rc, "gas_calc_spatialization")
         return out
+
+    def calc_spatialization_areas(self, cfgs, poses, listeners, slots, areas, listener_area_pos, cfg_index=None):
+        """Host-array form of gas_calc_spatialization_areas; returns (gas_params rows, reverb volumes [n][4][2])."""
+        cfgs = np.ascontiguousarray(cfgs, dtype=SPAT3D_CONFIG_DTYPE)
+        poses = np.ascontiguousarray(poses, dtype=POSE_DTYPE)
+        listeners = np.ascontiguousarray(listeners, dtype=LISTENER_DTYPE)
+        slots = np.ascontiguousarray(slots, dtype=np.uint32)
+        areas = np.ascontiguousarray(areas, dtype=AREA_SEND_DTYPE)
+        lap = np.ascontiguousarray(listener_area_pos, dtype=np.float32) if listener_area_pos is not None else None
+        ci = np.ascontiguousarray(cfg_index, dtype=np.uint32) if cfg_index is not None else None
+        n = len(slots)
+        assert len(areas) == n and (lap is None or lap.shape == (n, len(listeners), 3))
+        out = np.zeros(n, PARAMS_DTYPE)
+        reverb = np.full((n, 4, 2), np.nan, np.float32)
+        rc = self.lib.gas_calc_spatialization_areas(self.h, _np_ptr(cfgs), len(cfgs), _np_ptr(ci) if ci is not None else None, _np_ptr(poses), _np_ptr(listeners), len(listeners), _np_ptr(slots), n, _np_ptr(areas), _np_ptr(lap) if lap is not None else None, _np_ptr(out), _np_ptr(reverb), MEM_HOST)
+        self._check(rc, "gas_calc_spatialization_areas")
+        return out, reverb
 
     # ---- device-resident streams (SURVEY.md 8f#2) ----
     def stream_create(self, pcm):

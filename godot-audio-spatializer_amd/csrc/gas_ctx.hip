@@ -153,6 +153,9 @@ struct gas_ctx {
 	uint32_t *d_calc_slots = nullptr, *d_calc_cfgidx = nullptr;
 	gas_source_pose *d_calc_poses = nullptr;
 	gas_params *d_calc_out = nullptr;
+	gas_area_send *d_calc_areas = nullptr; // gas_calc_spatialization_areas staging (host-memory calls)
+	float *d_calc_lap = nullptr;
+	gas_audio_frame *d_calc_reverb = nullptr;
 
 	bool profiling = false;
 	std::vector<hipEvent_t> ev;
@@ -805,6 +808,9 @@ void gas_ctx_destroy(gas_ctx *c) {
 	(void)hipFree(c->d_calc_cfgidx);
 	(void)hipFree(c->d_calc_poses);
 	(void)hipFree(c->d_calc_out);
+	(void)hipFree(c->d_calc_areas);
+	(void)hipFree(c->d_calc_lap);
+	(void)hipFree(c->d_calc_reverb);
 	(void)hipHostFree(c->h_params);
 	(void)hipHostFree(c->h_upload);
 	(void)hipHostFree(c->h_upload_slots);
@@ -1127,6 +1133,10 @@ int gas_params_publish_batch(gas_ctx *c, const uint32_t *slots, const gas_params
 }
 
 int gas_calc_spatialization(gas_ctx *c, const gas_spatializer3d_config *cfgs, uint32_t n_cfgs, const uint32_t *cfg_index, const gas_source_pose *poses, const gas_listener *listeners, uint32_t n_listeners, const uint32_t *slots, uint32_t n, gas_params *out_params, int mem) {
+	return gas_calc_spatialization_areas(c, cfgs, n_cfgs, cfg_index, poses, listeners, n_listeners, slots, n, nullptr, nullptr, out_params, nullptr, mem);
+}
+
+int gas_calc_spatialization_areas(gas_ctx *c, const gas_spatializer3d_config *cfgs, uint32_t n_cfgs, const uint32_t *cfg_index, const gas_source_pose *poses, const gas_listener *listeners, uint32_t n_listeners, const uint32_t *slots, uint32_t n, const gas_area_send *areas, const float *listener_area_pos, gas_params *out_params, gas_audio_frame *out_reverb, int mem) {
 	if (!c || !cfgs || !poses || !slots || (n_listeners && !listeners) || (mem != GAS_MEM_HOST && mem != GAS_MEM_DEVICE)) {
 		return GAS_ERR_INVALID_ARGUMENT;
 	}
@@ -1180,9 +1190,33 @@ int gas_calc_spatialization(gas_ctx *c, const gas_spatializer3d_config *cfgs, ui
 			d_out = c->d_calc_out;
 		}
 	}
-	GAS_HIP(c, gas_launch_calc_spatialization(c->stream, c->d_calc_cfgs, cfg_index ? c->d_calc_cfgidx : nullptr, d_poses, c->d_calc_listeners, n_listeners, c->d_calc_slots, n, c->st.params, c->st.was_further, d_out));
+	const gas_area_send *d_areas = areas;
+	const float *d_lap = listener_area_pos;
+	gas_audio_frame *d_reverb = out_reverb;
+	if (mem == GAS_MEM_HOST && (areas || out_reverb)) { // staged like the poses; sized for the worst case once
+		if (!c->d_calc_areas) {
+			GAS_HIP(c, hipMalloc(&c->d_calc_areas, sizeof(gas_area_send) * c->cfg.max_sources));
+			GAS_HIP(c, hipMalloc(&c->d_calc_lap, sizeof(float) * 3 * GAS_MAX_LISTENERS * c->cfg.max_sources));
+			GAS_HIP(c, hipMalloc(&c->d_calc_reverb, sizeof(gas_audio_frame) * 4 * c->cfg.max_sources));
+		}
+		if (areas) {
+			GAS_HIP(c, hipMemcpyAsync(c->d_calc_areas, areas, sizeof(gas_area_send) * n, hipMemcpyHostToDevice, c->stream));
+			d_areas = c->d_calc_areas;
+		}
+		if (listener_area_pos) {
+			GAS_HIP(c, hipMemcpyAsync(c->d_calc_lap, listener_area_pos, sizeof(float) * 3 * n_listeners * n, hipMemcpyHostToDevice, c->stream));
+			d_lap = c->d_calc_lap;
+		}
+		if (out_reverb) {
+			d_reverb = c->d_calc_reverb;
+		}
+	}
+	GAS_HIP(c, gas_launch_calc_spatialization(c->stream, c->d_calc_cfgs, cfg_index ? c->d_calc_cfgidx : nullptr, d_poses, c->d_calc_listeners, n_listeners, c->d_calc_slots, n, c->st.params, c->st.was_further, d_out, d_areas, d_lap, d_reverb));
 	if (mem == GAS_MEM_HOST && out_params) {
 		GAS_HIP(c, hipMemcpyAsync(out_params, c->d_calc_out, sizeof(gas_params) * n, hipMemcpyDeviceToHost, c->stream));
+	}
+	if (mem == GAS_MEM_HOST && out_reverb) {
+		GAS_HIP(c, hipMemcpyAsync(out_reverb, c->d_calc_reverb, sizeof(gas_audio_frame) * 4 * n, hipMemcpyDeviceToHost, c->stream));
 	}
 	GAS_HIP(c, hipStreamSynchronize(c->stream)); // the host staging arrays are the caller's
 	for (uint32_t i = 0; i < n; i++) {

@@ -99,7 +99,7 @@ void gas_make_twiddles(float2 *host_tw /* [64][16] */);
 
 hipError_t gas_launch_mix_reduce(hipStream_t stream, const float *partials, uint32_t p_count, uint32_t p_stride, uint32_t channels, uint32_t frames, gas_audio_frame *out);
 hipError_t gas_launch_scatter_params(hipStream_t stream, gas_params *table, const gas_params *upload, const uint32_t *slots, uint32_t n);
-hipError_t gas_launch_calc_spatialization(hipStream_t stream, const gas_spatializer3d_config *cfgs, const uint32_t *cfg_index, const gas_source_pose *poses, const gas_listener *listeners, uint32_t n_listeners, const uint32_t *slots, uint32_t n, gas_params *table, uint8_t *was_further, gas_params *out_params);
+hipError_t gas_launch_calc_spatialization(hipStream_t stream, const gas_spatializer3d_config *cfgs, const uint32_t *cfg_index, const gas_source_pose *poses, const gas_listener *listeners, uint32_t n_listeners, const uint32_t *slots, uint32_t n, gas_params *table, uint8_t *was_further, gas_params *out_params, const gas_area_send *areas = nullptr, const float *listener_area_pos = nullptr, gas_audio_frame *out_reverb = nullptr);
 hipError_t gas_launch_sample_sources(hipStream_t stream, gas_cursor *cursors, const uint32_t *slots, uint32_t n, uint32_t frames, const float *fade_env, gas_audio_frame *rows);
 hipError_t gas_launch_noop(hipStream_t stream); // event-timer calibration
 #define GAS_DIR_ORDER_SEGMENT 8192

@@ -123,7 +123,53 @@ __device__ void calc_output_vol(const gas_spatializer3d_config &cfg, V3 dir, flo
 	out[0][1] = volumes[1];
 }
 
-__global__ __launch_bounds__(256) void k_calc_spatialization(const gas_spatializer3d_config *__restrict__ cfgs, const uint32_t *__restrict__ cfg_index, const gas_source_pose *__restrict__ poses, const gas_listener *__restrict__ listeners, uint32_t n_listeners, const uint32_t *__restrict__ slots, uint32_t n, gas_params *__restrict__ table, uint8_t *__restrict__ was_further_tab, gas_params *__restrict__ out_params) {
+// calc_reverb_vol, audio_spatializer_3d.cpp:154-197 (oracle: calc_reverb_vol)
+__device__ void calc_reverb_vol(const gas_spatializer3d_config &cfg, const gas_source_pose &s, const gas_area_send &area, V3 lap, const float (&direct)[4][2], float (&rv)[4][2]) {
+#pragma unroll
+	for (int i = 0; i < 4; i++) {
+		rv[i][0] = 0.0f;
+		rv[i][1] = 0.0f;
+	}
+	const float uniformity = area.reverb_uniformity;
+	const float area_send = area.reverb_amount;
+	if (uniformity > 0.0f) {
+		const float distance = v3_len(lap);
+		const float attenuation = db_to_linear(attenuation_db(cfg, s, distance)); // :163
+		const int chan_count = cfg.speaker_mode + 1;
+		const float center = chan_count == 1 ? 0.5f : (chan_count == 2 ? 0.25f : (chan_count == 3 ? 0.16666f : 0.125f)); // :166
+		if (attenuation < 1.0f) { // :170-181
+			V3 rev_pos = lap;
+			rev_pos.y = 0;
+			rev_pos = v3_normalized(rev_pos);
+			calc_output_vol(cfg, rev_pos, rv);
+			for (int i = 0; i < chan_count; i++) {
+				rv[i][0] = rv[i][0] + (center - rv[i][0]) * attenuation;
+				rv[i][1] = rv[i][1] + (center - rv[i][1]) * attenuation;
+			}
+		} else {
+			for (int i = 0; i < chan_count; i++) {
+				rv[i][0] = center;
+				rv[i][1] = center;
+			}
+		}
+		for (int i = 0; i < chan_count; i++) { // :187-190
+#pragma unroll
+			for (int e = 0; e < 2; e++) {
+				const float to = rv[i][e] * attenuation;
+				const float v = direct[i][e] + (to - direct[i][e]) * uniformity;
+				rv[i][e] = v * area_send;
+			}
+		}
+	} else {
+#pragma unroll
+		for (int i = 0; i < 4; i++) { // :193-195
+			rv[i][0] = direct[i][0] * area_send;
+			rv[i][1] = direct[i][1] * area_send;
+		}
+	}
+}
+
+__global__ __launch_bounds__(256) void k_calc_spatialization(const gas_spatializer3d_config *__restrict__ cfgs, const uint32_t *__restrict__ cfg_index, const gas_source_pose *__restrict__ poses, const gas_listener *__restrict__ listeners, uint32_t n_listeners, const uint32_t *__restrict__ slots, uint32_t n, gas_params *__restrict__ table, uint8_t *__restrict__ was_further_tab, gas_params *__restrict__ out_params, const gas_area_send *__restrict__ areas, const float *__restrict__ listener_area_pos, gas_audio_frame *__restrict__ out_reverb) {
 	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= n) {
 		return;
@@ -143,6 +189,14 @@ __global__ __launch_bounds__(256) void k_calc_spatialization(const gas_spatializ
 	float linear_attenuation = 0.0f, cutoff = 5000.0f; // a fresh SpatializerParameters3D (audio_spatializer_3d.h:67-68)
 	float best_mult = -1.0f;
 	V3 best_local{ 0, 0, -1 };
+	// the Area3D branches (:349-353, :364-370, :399-402); areas == nullptr: the source sits in no area
+	gas_area_send area{};
+	if (areas) {
+		area = areas[i];
+	}
+	const bool area_reverb = area.present != 0 && area.using_reverb_bus != 0;
+	const bool area_uniform = area_reverb && area.reverb_uniformity > 0 && listener_area_pos != nullptr;
+	float reverb_volume[4][2] = { { 0, 0 }, { 0, 0 }, { 0, 0 }, { 0, 0 } };
 
 	for (uint32_t li = 0; li < n_listeners; li++) {
 		const gas_listener L = listeners[li];
@@ -150,8 +204,18 @@ __global__ __launch_bounds__(256) void k_calc_spatialization(const gas_spatializ
 		const V3 local_pos = basis_xform_inv(L.basis, rel); // :343
 		const float dist = v3_len(local_pos);
 		float multiplier = db_to_linear(attenuation_db(cfg, s, dist)); // :359
+		V3 lap{ 0, 0, 0 };
+		if (area_uniform) {
+			const float *q = listener_area_pos + ((size_t)i * n_listeners + li) * 3;
+			lap = V3{ q[0], q[1], q[2] };
+		}
 		if (cfg.max_distance > 0) { // :361-374
-			if (dist > cfg.max_distance) {
+			float total_max = cfg.max_distance;
+			if (area_uniform) {
+				const float l = v3_len(lap);
+				total_max = total_max > l ? total_max : l;
+			}
+			if (dist > total_max || total_max > cfg.max_distance) {
 				continue;
 			}
 			const double m = 1.0 - (double)(dist / cfg.max_distance);
@@ -177,6 +241,15 @@ __global__ __launch_bounds__(256) void k_calc_spatialization(const gas_spatializ
 			tmp[k][1] = multiplier * tmp[k][1];
 			output_volume[k][0] = output_volume[k][0] > tmp[k][0] ? output_volume[k][0] : tmp[k][0];
 			output_volume[k][1] = output_volume[k][1] > tmp[k][1] ? output_volume[k][1] : tmp[k][1];
+		}
+		if (area_reverb) { // :399-402
+			float tr[4][2];
+			calc_reverb_vol(cfg, s, area, lap, tmp, tr);
+#pragma unroll
+			for (int k = 0; k < 4; k++) {
+				reverb_volume[k][0] = reverb_volume[k][0] > tr[k][0] ? reverb_volume[k][0] : tr[k][0];
+				reverb_volume[k][1] = reverb_volume[k][1] > tr[k][1] ? reverb_volume[k][1] : tr[k][1];
+			}
 		}
 		if (multiplier > best_mult) {
 			best_mult = multiplier;
@@ -226,6 +299,12 @@ __global__ __launch_bounds__(256) void k_calc_spatialization(const gas_spatializ
 		ei = ei < 0 ? 0 : (ei > (long long)cfg.hrtf_n_el - 1 ? (long long)cfg.hrtf_n_el - 1 : ei);
 		P->hrtf_dir = (uint32_t)(ei * cfg.hrtf_n_az + ai);
 	}
+	if (out_reverb) { // what the reference sends to the area's reverb bus (:451-452)
+#pragma unroll
+		for (int k = 0; k < 4; k++) {
+			out_reverb[(size_t)i * 4 + k] = gas_audio_frame{ reverb_volume[k][0], reverb_volume[k][1] };
+		}
+	}
 	if (out_params) {
 		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
 		out_params[i] = *P; // this lane wrote every field it reads back or they were already in the table
@@ -234,10 +313,10 @@ __global__ __launch_bounds__(256) void k_calc_spatialization(const gas_spatializ
 
 } // namespace
 
-hipError_t gas_launch_calc_spatialization(hipStream_t stream, const gas_spatializer3d_config *cfgs, const uint32_t *cfg_index, const gas_source_pose *poses, const gas_listener *listeners, uint32_t n_listeners, const uint32_t *slots, uint32_t n, gas_params *table, uint8_t *was_further, gas_params *out_params) {
+hipError_t gas_launch_calc_spatialization(hipStream_t stream, const gas_spatializer3d_config *cfgs, const uint32_t *cfg_index, const gas_source_pose *poses, const gas_listener *listeners, uint32_t n_listeners, const uint32_t *slots, uint32_t n, gas_params *table, uint8_t *was_further, gas_params *out_params, const gas_area_send *areas, const float *listener_area_pos, gas_audio_frame *out_reverb) {
 	if (n == 0) {
 		return hipSuccess;
 	}
-	hipLaunchKernelGGL(k_calc_spatialization, dim3((n + 255) / 256), dim3(256), 0, stream, cfgs, cfg_index, poses, listeners, n_listeners, slots, n, table, was_further, out_params);
+	hipLaunchKernelGGL(k_calc_spatialization, dim3((n + 255) / 256), dim3(256), 0, stream, cfgs, cfg_index, poses, listeners, n_listeners, slots, n, table, was_further, out_params, areas, listener_area_pos, out_reverb);
 	return hipGetLastError();
 }

@@ -250,6 +250,24 @@ typedef struct gas_listener { /* orthonormalized global transform of the camera 
  * [n] gas_params, may be NULL) are host or device pointers according to `mem`.  Physics thread. */
 int gas_calc_spatialization(gas_ctx *ctx, const gas_spatializer3d_config *cfgs, uint32_t n_cfgs, const uint32_t *cfg_index, const gas_source_pose *poses, const gas_listener *listeners, uint32_t n_listeners, const uint32_t *slots, uint32_t n, gas_params *out_params, int mem);
 
+/* The same with the Area3D branches of calculate_spatialization.  The physics queries stay on the
+ * host: which area a source sits in (audio_spatializer_3d.cpp:208-256) and, per listener, the closest point of the
+ * area volume in that listener's space (:350-353).  The arithmetic is batched: the widened / vetoed max-distance
+ * test (:364-370) and calc_reverb_vol (:154-197), max-combined over the listeners (:399-402) into the volumes the
+ * reference sends to the area's reverb bus (:451-452).  Which bus that is (override / reverb bus names) is the
+ * caller's bookkeeping. */
+typedef struct gas_area_send {
+	uint32_t using_reverb_bus; /* Area3D::is_using_reverb_bus() */
+	float reverb_uniformity; /* Area3D::get_reverb_uniformity() */
+	float reverb_amount; /* Area3D::get_reverb_amount() */
+	uint32_t present; /* 0: the source sits in no area (other fields ignored) */
+} gas_area_send;
+
+/* areas [n], listener_area_pos [n][n_listeners][3] (may be NULL when no area has uniformity > 0) and out_reverb
+ * [n][4] AudioFrames (may be NULL) are host or device pointers according to `mem`, like poses.  areas == NULL is
+ * gas_calc_spatialization. */
+int gas_calc_spatialization_areas(gas_ctx *ctx, const gas_spatializer3d_config *cfgs, uint32_t n_cfgs, const uint32_t *cfg_index, const gas_source_pose *poses, const gas_listener *listeners, uint32_t n_listeners, const uint32_t *slots, uint32_t n, const gas_area_send *areas, const float *listener_area_pos, gas_params *out_params, gas_audio_frame *out_reverb, int mem);
+
 
 /* ---- device-resident source sampling ------------------------------------------------
  * The step in front of the path: AudioStreamPlayback::mix into the 64-frame lookahead window with the

@@ -212,6 +212,8 @@ def lib():
     L.gaso_batch_block.argtypes = [C.c_int, C.c_int, C.c_void_p, C.POINTER(BatchState), C.POINTER(Hrtf), C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]
     L.gaso_calc_spatialization.restype = C.c_int
     L.gaso_calc_spatialization.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int32), C.c_void_p]
+    L.gaso_calc_spatialization_area.restype = C.c_int
+    L.gaso_calc_spatialization_area.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int32), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.gaso_hrtf_prepare.argtypes = [C.POINTER(Hrtf), C.c_int]
     L.gaso_hrtf_release.argtypes = [C.POINTER(Hrtf)]
     L.gaso_hrtf_ols_radix2.argtypes = [C.POINTER(Params), C.POINTER(FxState), C.POINTER(Hrtf), C.c_void_p, C.c_void_p, C.c_int]
@@ -301,3 +303,27 @@ def calc_spatialization(cfgs, cfg_index, poses, listeners, was_further, out_para
         in_range[i] = L.gaso_calc_spatialization(cfgs.ctypes.data + 64 * ci, poses.ctypes.data + 48 * i, listeners.ctypes.data, len(listeners), C.byref(wf), out_params.ctypes.data + 128 * i)
         was_further[i] = wf.value
     return in_range
+
+
+AREA_SEND_DTYPE = np.dtype([("using_reverb_bus", np.uint32), ("reverb_uniformity", np.float32), ("reverb_amount", np.float32), ("present", np.uint32)])
+
+
+def calc_spatialization_areas(cfgs, cfg_index, poses, listeners, was_further, areas, listener_area_pos, out_params):
+    """Row-by-row gaso_calc_spatialization_area.  areas: AREA_SEND_DTYPE[n]; listener_area_pos: float32 [n][L][3] or None.
+    Returns (in_range[n], reverb[n][4][2])."""
+    n = len(poses)
+    L = lib()
+    in_range = np.zeros(n, np.int32)
+    areas = np.ascontiguousarray(areas, dtype=AREA_SEND_DTYPE)
+    lap = np.ascontiguousarray(listener_area_pos, dtype=np.float32) if listener_area_pos is not None else None
+    reverb = np.zeros((n, 4, 2), np.float32)
+    nl = len(listeners)
+    for i in range(n):
+        ci = int(cfg_index[i]) if cfg_index is not None else 0
+        wf = C.c_int32(int(was_further[i]))
+        in_range[i] = L.gaso_calc_spatialization_area(
+            C.c_void_p(cfgs.ctypes.data + 64 * ci), C.c_void_p(poses.ctypes.data + 48 * i), C.c_void_p(listeners.ctypes.data), nl, C.byref(wf),
+            C.c_void_p(areas.ctypes.data + 16 * i), C.c_void_p(lap.ctypes.data + 12 * nl * i) if lap is not None else None,
+            C.c_void_p(out_params.ctypes.data + 128 * i), C.c_void_p(reverb.ctypes.data + 32 * i))
+        was_further[i] = wf.value
+    return in_range, reverb

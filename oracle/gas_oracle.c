@@ -915,7 +915,63 @@ static void calc_output_vol(const gaso_spat3d_config *cfg, v3 source_dir, float 
 	out[0][1] = volumes[1];
 }
 
+/* calc_reverb_vol, audio_spatializer_3d.cpp:154-197.  [ENGINE] Vector2::lerp(to, w) = this + (to - this) * w per
+ * component in f32; AudioServer::get_channel_count() = speaker_mode + 1. */
+static void calc_reverb_vol(const gaso_spat3d_config *cfg, const gaso_source_pose *s, const gaso_area_send *area, v3 listener_area_pos, float direct_path_vol[4][2], float reverb_vol[4][2]) {
+	for (int i = 0; i < 4; i++) { /* :155-156 */
+		reverb_vol[i][0] = 0.0f;
+		reverb_vol[i][1] = 0.0f;
+	}
+	const float uniformity = area->reverb_uniformity;
+	const float area_send = area->reverb_amount;
+	if (uniformity > 0.0f) {
+		const float distance = v3_len(listener_area_pos);
+		const float attenuation = gaso_db_to_linear(get_attenuation_db(cfg, s, distance)); /* :163 */
+		static const float center_val[4] = { 0.5f, 0.25f, 0.16666f, 0.125f }; /* :166 */
+		const int chan_count = cfg->speaker_mode + 1;
+		const float center = center_val[chan_count - 1];
+		if (attenuation < 1.0f) { /* :170-181: pan the uniform sound */
+			v3 rev_pos = listener_area_pos;
+			rev_pos.y = 0;
+			rev_pos = v3_normalized(rev_pos);
+			calc_output_vol(cfg, rev_pos, reverb_vol);
+			for (int i = 0; i < chan_count; i++) {
+				reverb_vol[i][0] = reverb_vol[i][0] + (center - reverb_vol[i][0]) * attenuation;
+				reverb_vol[i][1] = reverb_vol[i][1] + (center - reverb_vol[i][1]) * attenuation;
+			}
+		} else {
+			for (int i = 0; i < chan_count; i++) {
+				reverb_vol[i][0] = center;
+				reverb_vol[i][1] = center;
+			}
+		}
+		for (int i = 0; i < chan_count; i++) { /* :187-190 */
+			for (int e = 0; e < 2; e++) {
+				const float to = reverb_vol[i][e] * attenuation;
+				float v = direct_path_vol[i][e] + (to - direct_path_vol[i][e]) * uniformity;
+				reverb_vol[i][e] = v * area_send;
+			}
+		}
+	} else {
+		for (int i = 0; i < 4; i++) { /* :193-195 */
+			reverb_vol[i][0] = direct_path_vol[i][0] * area_send;
+			reverb_vol[i][1] = direct_path_vol[i][1] * area_send;
+		}
+	}
+}
+
 int gaso_calc_spatialization(const gaso_spat3d_config *cfg, const gaso_source_pose *s, const gaso_listener *listeners, int n_listeners, int32_t *was_further, gaso_params *out) {
+	float reverb[4][2];
+	return gaso_calc_spatialization_area(cfg, s, listeners, n_listeners, was_further, NULL, NULL, out, reverb);
+}
+
+int gaso_calc_spatialization_area(const gaso_spat3d_config *cfg, const gaso_source_pose *s, const gaso_listener *listeners, int n_listeners, int32_t *was_further, const gaso_area_send *area, const float *listener_area_pos, gaso_params *out, float (*out_reverb)[2]) {
+	if (area && !area->present) {
+		area = NULL;
+	}
+	const int area_reverb = area && area->using_reverb_bus;
+	const int area_uniform = area_reverb && area->reverb_uniformity > 0 && listener_area_pos; /* :349,365 */
+	float reverb_volume[4][2] = { { 0 } };
 	v3 global_pos = { s->position[0], s->position[1], s->position[2] };
 	v3 linear_velocity = { 0, 0, 0 };
 	if (cfg->doppler_tracking != 0) { /* :295-297 */
@@ -937,9 +993,19 @@ int gaso_calc_spatialization(const gaso_spat3d_config *cfg, const gaso_source_po
 		v3 local_pos = basis_xform_inv(L->basis, rel); /* :343 */
 		float dist = v3_len(local_pos);
 		float multiplier = gaso_db_to_linear(get_attenuation_db(cfg, s, dist)); /* :359 */
-		if (cfg->max_distance > 0) { /* :361-374 (no Area3D: total_max == max_distance) */
+		v3 lap = { 0, 0, 0 };
+		if (area_uniform) { /* :350-353 */
+			lap.x = listener_area_pos[li * 3 + 0];
+			lap.y = listener_area_pos[li * 3 + 1];
+			lap.z = listener_area_pos[li * 3 + 2];
+		}
+		if (cfg->max_distance > 0) { /* :361-374 */
 			float total_max = cfg->max_distance;
-			if (dist > total_max) {
+			if (area_uniform) { /* :365-367 */
+				const float l = v3_len(lap);
+				total_max = total_max > l ? total_max : l;
+			}
+			if (dist > total_max || total_max > cfg->max_distance) { /* :369 */
 				continue;
 			}
 			double m = 1.0 - (dist / cfg->max_distance);
@@ -966,6 +1032,14 @@ int gaso_calc_spatialization(const gaso_spat3d_config *cfg, const gaso_source_po
 			/* _apply_max_volume (:257-265): MAX(tgt, src) = tgt > src ? tgt : src */
 			output_volume[k][0] = output_volume[k][0] > tmp_volume[k][0] ? output_volume[k][0] : tmp_volume[k][0];
 			output_volume[k][1] = output_volume[k][1] > tmp_volume[k][1] ? output_volume[k][1] : tmp_volume[k][1];
+		}
+		if (area_reverb) { /* :399-402 */
+			float tmp_reverb[4][2];
+			calc_reverb_vol(cfg, s, area, lap, tmp_volume, tmp_reverb);
+			for (int k = 0; k < 4; k++) {
+				reverb_volume[k][0] = reverb_volume[k][0] > tmp_reverb[k][0] ? reverb_volume[k][0] : tmp_reverb[k][0];
+				reverb_volume[k][1] = reverb_volume[k][1] > tmp_reverb[k][1] ? reverb_volume[k][1] : tmp_reverb[k][1];
+			}
 		}
 		if (multiplier > best_mult) {
 			best_mult = multiplier;
@@ -997,6 +1071,8 @@ int gaso_calc_spatialization(const gaso_spat3d_config *cfg, const gaso_source_po
 	for (int k = 0; k < 4; k++) { /* :469 */
 		out->mix_volumes[k][0] = output_volume[k][0];
 		out->mix_volumes[k][1] = output_volume[k][1];
+		out_reverb[k][0] = reverb_volume[k][0];
+		out_reverb[k][1] = reverb_volume[k][1];
 	}
 	const int skip_setting_volumes = !has_any_listener_in_range && *was_further; /* :472-479 */
 	*was_further = !has_any_listener_in_range;

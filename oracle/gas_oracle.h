@@ -224,6 +224,22 @@ typedef struct gaso_listener { /* listener_node->get_global_transform().orthonor
  * Returns has_any_listener_in_range. */
 int gaso_calc_spatialization(const gaso_spat3d_config *cfg, const gaso_source_pose *src, const gaso_listener *listeners, int n_listeners, int32_t *was_further, gaso_params *out);
 
+/* The Area3D a source sits in (found by the physics query of audio_spatializer_3d.cpp:208-256; only the numbers the
+ * arithmetic reads).  present == 0: no area. */
+typedef struct gaso_area_send {
+	uint32_t using_reverb_bus; /* Area3D::is_using_reverb_bus(), :349,365,399 */
+	float reverb_uniformity; /* :158 */
+	float reverb_amount; /* :159 */
+	uint32_t present;
+} gaso_area_send;
+
+/* gaso_calc_spatialization with the Area3D branches: listener_area_pos[li][3] is the closest point of the area
+ * volume to listener li in that listener's space (:350-353, physics query + transform, host side); it widens or
+ * vetoes the max-distance test (:364-370) and feeds calc_reverb_vol (:154-197), whose per-listener results are
+ * max-combined into out_reverb[4][2] (:399-402) -- the volumes the reference sends to the area's reverb bus (:451-452).
+ * area == NULL or !present: identical to gaso_calc_spatialization, out_reverb zeroed. */
+int gaso_calc_spatialization_area(const gaso_spat3d_config *cfg, const gaso_source_pose *src, const gaso_listener *listeners, int n_listeners, int32_t *was_further, const gaso_area_send *area, const float *listener_area_pos, gaso_params *out, float (*out_reverb)[2]);
+
 /* ---- batched convenience used by the GPU parity tests and the CPU baseline ----
  * One callback over n_src independent sources of one kind, each row of src is
  * that source's already-windowed F frames (what process_frames/mix_channel see).

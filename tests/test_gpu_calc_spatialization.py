@@ -76,6 +76,49 @@ def test_calc_spatialization_matches_oracle(gas, ob, n_listeners):
             assert got["hrtf_dir"].max() < 32 * 9
 
 
+@pytest.mark.parametrize("n_listeners", [1, 3])
+def test_calc_spatialization_area_branches_match_oracle(gas, ob, n_listeners):
+    """sources inside Area3Ds with a reverb send.  The closest area point per listener widens or
+    vetoes the max-distance test (audio_spatializer_3d.cpp:364-370) and calc_reverb_vol (:154-197) yields the
+    reverb-bus volumes, max-combined over the listeners (:399-402); every speaker mode, uniformity 0 and > 0."""
+    K = gas.capi
+    rng = np.random.default_rng(77)
+    n, n_cfgs = 3000, 24
+    cfgs, poses, listeners, cfg_index = scene(gas, rng, n, n_listeners, n_cfgs)
+    cfgs["panning_strength"] = 1.0  # keeps SPCAP finite for most directions
+    areas = np.zeros(n, K.AREA_SEND_DTYPE)
+    areas["present"] = rng.random(n) < 0.8
+    areas["using_reverb_bus"] = rng.random(n) < 0.7
+    areas["reverb_uniformity"] = np.where(rng.random(n) < 0.4, 0.0, rng.uniform(0.05, 1.0, n))
+    areas["reverb_amount"] = rng.uniform(0.0, 1.0, n)
+    lap = (rng.standard_normal((n, n_listeners, 3)) * np.exp(rng.uniform(np.log(0.2), np.log(90.0), (n, n_listeners, 1)))).astype(np.float32)
+    lap[::11] = 0.0  # the listener stands inside the area
+    with gas.SpatializerContext(max_sources=n, frames=512, channel_count=4) as ctx:
+        slots = ctx.source_alloc_many(n, K.KIND_3D_MIX)
+        was_further = np.zeros(n, np.int32)
+        for tick in range(2):
+            if tick == 1:
+                poses["position"] *= 2.0
+            got, rev = ctx.calc_spatialization_areas(cfgs, poses, listeners, slots, areas, lap, cfg_index=cfg_index)
+            want = np.zeros(n, ob.PARAMS_DTYPE)
+            in_range, wrev = ob.calc_spatialization_areas(cfgs, cfg_index, poses, listeners, was_further, areas, lap, want)
+            ok = np.isfinite(want["mix_volumes"]).all(axis=(1, 2)) & np.isfinite(wrev).all(axis=(1, 2))
+            assert ok.mean() > 0.6
+            np.testing.assert_array_equal(np.isfinite(got["mix_volumes"]).all(axis=(1, 2)) & np.isfinite(rev).all(axis=(1, 2)), ok)
+            np.testing.assert_allclose(got["mix_volumes"][ok], want["mix_volumes"][ok], rtol=3e-5, atol=1e-7)
+            np.testing.assert_allclose(rev[ok], wrev[ok], rtol=5e-5, atol=1e-7)
+            np.testing.assert_array_equal(got["update_parameters"], want["update_parameters"])
+            np.testing.assert_allclose(got["linear_attenuation"], want["linear_attenuation"], rtol=3e-5, atol=1e-8)
+            # the branches are all taken: areas that veto a listener, areas that send, sources without an area
+            sending = (areas["present"] != 0) & (areas["using_reverb_bus"] != 0)
+            assert (np.abs(wrev[sending & ok]).max(axis=(1, 2)) > 0).mean() > 0.2
+            assert not np.abs(wrev[~sending]).any() and not np.abs(rev[~sending]).any()
+        # without areas the new entry is the old one
+        plain = ctx.calc_spatialization(cfgs, poses, listeners, slots, cfg_index=cfg_index)
+        same, zero = ctx.calc_spatialization_areas(cfgs, poses, listeners, slots, np.zeros(n, K.AREA_SEND_DTYPE), None, cfg_index=cfg_index)
+        assert plain.tobytes() == same.tobytes() and not zero.any()
+
+
 def test_generated_parameters_drive_the_mix(gas, ob):
     """The parameters the device generated are the ones the next callback mixes with (no host publish)."""
     from godot_audio_spatializer_amd import synth
