@@ -149,3 +149,30 @@ def test_reverb_send_closed_forms():
     o = np.zeros(1, ob.PARAMS_DTYPE)
     inr, rv = ob.calc_spatialization_areas(far, None, pose, lis, np.zeros(1, np.int32), _areas(uniformity=0.5), np.array([[[0, 0, -30.0]]], np.float32), o)
     assert inr[0] == 0 and not o["mix_volumes"].any() and not rv.any()
+
+
+@pytest.mark.parametrize("speaker_mode", [1, 2, 3])
+def test_surround_spcap_closed_form(speaker_mode):
+    """SPCAP (audio_spatializer_3d.cpp:57-98, :903-938) in numpy: gain_k = 0.5 (1 + d_k . s)^t / eff_k, volumes =
+    sqrt(g_k^2 / sum g^2); tightness = 2 * global_panning_strength * panning_strength (:117-119); the direction is
+    passed as it is, not normalised (:391); LFE slot always 1 (:90)."""
+    dirs = np.array([(-1, 0, -1), (1, 0, -1), (0, 0, -1), (-1, 0, 1), (1, 0, 1), (-1, 0, 0), (1, 0, 0)], np.float64)
+    dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
+    count = {1: 3, 2: 5, 3: 7}[speaker_mode]
+    d = dirs[:count].astype(np.float32).astype(np.float64)
+    eff = (0.5 * (1.0 + d @ d.T)).sum(axis=1)
+    cfg = _cfg(attenuation_model=3, speaker_mode=speaker_mode, panning_strength=1.5, global_panning_strength=0.5, max_distance=0.0)
+    tight = 0.5 * 2.0 * 1.5
+    for pos in [(0.3, 0.1, -0.4), (-0.6, 0.2, 0.5), (0.05, -0.3, -0.9)]:  # |pos| < 1 keeps 1 + d.s positive
+        out = np.zeros(1, ob.PARAMS_DTYPE)
+        ob.calc_spatialization(cfg, None, _pose(pos), _listener(), np.zeros(1, np.int32), out)
+        g = 0.5 * (1.0 + d @ np.float64(np.float32(pos))) ** tight / eff
+        v = np.sqrt(g * g / (g * g).sum())
+        want = np.zeros((4, 2))
+        want[0] = v[0], v[1]
+        want[1] = v[2], 1.0
+        if count >= 5:
+            want[2] = v[3], v[4]
+        if count >= 7:
+            want[3] = v[5], v[6]
+        np.testing.assert_allclose(out["mix_volumes"][0], want, rtol=2e-5, atol=1e-7)
