@@ -214,13 +214,11 @@ hipError_t gas_launch_dir_order(hipStream_t stream, const gas_group_args &g, con
 	}
 	const uint32_t d2 = (dirs + 1) & ~1u; // keeps the u16 table's zeroing loop word-aligned
 	const size_t lds = (size_t)d2 * 4 + (size_t)DIR_WAVES * d2 * 2;
-	static bool raised = false; // > 64 KiB of dynamic LDS needs the opt-in, once per process
-	if (!raised) {
+	if (lds > 48 * 1024) { // large dynamic LDS needs the opt-in, per device: cheap enough to repeat (the sort runs per publish)
 		hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_dir_order), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 		if (e != hipSuccess) {
 			return e;
 		}
-		raised = true;
 	}
 	hipLaunchKernelGGL(k_dir_order, dim3((g.n + DIR_SEG - 1) / DIR_SEG), dim3(DIR_WAVES * 64), lds, stream, g, params, fresh, d2, order);
 	return hipGetLastError();

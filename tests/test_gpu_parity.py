@@ -183,7 +183,7 @@ def test_biquad_extreme_filter_settings(gas, ob, cutoff, gain):
     run_pair(gas, ob, gas.capi.KIND_EFFECT, (gas.capi.FX_HIGHSHELF,), 40, 512, 6, params_hook=hook)
 
 
-@pytest.mark.parametrize("n,dirs,chain,frames,ring", [(1100, 32, (3,), 512, 0), (9000, 64, (3,), 256, 0), (700, 16, (2, 3), 256, 4096)])
+@pytest.mark.parametrize("n,dirs,chain,frames,ring", [(1100, 32, (3,), 512, 0), (9000, 64, (3,), 256, 0), (700, 16, (2, 3), 256, 4096), (7000, 3000, (3,), 256, 0)])
 def test_hrtf_direction_ordered_groups(gas, ob, n, dirs, chain, frames, ring):
     """Frequency-domain groups large enough to be direction-ordered (k_dir_order): sources sharing an HRIR
     direction are summed before ONE forward FFT.  Callbacks alternate between fresh parameters (order rebuilt),
