@@ -625,6 +625,17 @@ __device__ __forceinline__ void hrtf_body(float2 *lds_all, const uint32_t wg, co
 		if constexpr (SRC_PCM) {
 			lm.cur = cursors[lm.slot];
 		}
+		// per-source state that does not depend on the audio, written once for all of the wave's sources (one lane
+		// each) instead of by lane 0 inside the source loop
+		if (!(GAS_ABL & 64)) {
+			st.hrtf_prev_gain[lm.slot] = lm.g1;
+			if constexpr (XFADE) {
+				st.hrtf_prev_dir[lm.slot] = lm.dir + 1;
+			}
+			if constexpr (!PEAKS) { // "not measured": never passes the gate (audio_spatializer.cpp:464-469)
+				*reinterpret_cast<float2 *>(g.peaks + (size_t)lm.row * 2) = make_float2(__builtin_inff(), __builtin_inff());
+			}
+		}
 	}
 	if (first < last) {
 #pragma unroll
@@ -727,10 +738,6 @@ __device__ __forceinline__ void hrtf_body(float2 *lds_all, const uint32_t wg, co
 			store_history<HQ>(st.hrtf_hist + (size_t)m.slot * HL, lane, &xq[FQ]);
 		}
 		if (lane == 0 && !(GAS_ABL & 64)) {
-			st.hrtf_prev_gain[m.slot] = m.g1;
-			if constexpr (XFADE) {
-				st.hrtf_prev_dir[m.slot] = m.dir + 1;
-			}
 			if constexpr (SRC_PCM) {
 				if (m.hf) { // advance the playback cursor (audio_spatializer.cpp:378,398)
 					cursors[m.slot].pos = m.pos + m.mixed;
@@ -889,10 +896,6 @@ __device__ __forceinline__ void hrtf_body(float2 *lds_all, const uint32_t wg, co
 					issue_spectra(tab.spec, mn.dir, lane, hs);
 				}
 				}
-			}
-			if (lane == 0 && !(GAS_ABL & 64)) {
-				g.peaks[(size_t)m.row * 2] = __builtin_inff();
-				g.peaks[(size_t)m.row * 2 + 1] = __builtin_inff();
 			}
 		}
 		}
