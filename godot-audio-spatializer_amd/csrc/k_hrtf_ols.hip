@@ -584,7 +584,10 @@ __device__ __forceinline__ void hrtf_body(float2 *lds_all, const uint32_t wg, co
 
 	// in-flight buffers of the software pipeline
 	float4 hs[8]; // spectra (HL.re, HL.im, HR.re, HR.im) of bins lane + 64 j
-	constexpr int STAGES = 1; // 2 was measured no faster (17.7 vs 16.6 us at 8192 sources): the loop is not latency-bound per wave
+#ifndef GAS_HRTF_STAGES
+#define GAS_HRTF_STAGES 1 // 2 was measured no faster (17.7 vs 16.6 us at 8192 sources): the loop is not latency-bound per wave
+#endif
+	constexpr int STAGES = (WITH_ER || SRC_PCM || XFADE) ? 1 : GAS_HRTF_STAGES;
 	gas_audio_frame raw[STAGES][FQ]; // frames lane + 64 q of the source row
 	float rawh[STAGES][HQ]; // history samples lane + 64 q
 	// Prologue, ordered so that no load waits behind one it does not depend on:

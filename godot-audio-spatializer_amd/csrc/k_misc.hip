@@ -93,6 +93,9 @@ __global__ void k_noop() {
 // contiguous entries [w*512, w*512+512) of the segment and walks them 64 at a time; lanes with equal keys find each
 // other with one ballot per key bit; hist[w][key] counts the wave's entries per key in order; a per-key prefix over
 // the 16 waves and one exclusive scan over the keys give every entry its destination.
+#ifndef GAS_DIRSORT_ABL
+#define GAS_DIRSORT_ABL 0 // timing experiments (tools/dirsort_probe.sh): 1 synthetic keys (no loads), 2 no rank loop; both keep every index in range
+#endif
 constexpr int DIR_SEG = GAS_DIR_ORDER_SEGMENT;
 constexpr int DIR_WAVES = 16;
 constexpr int DIR_ROUNDS = DIR_SEG / (DIR_WAVES * 64);
@@ -123,15 +126,15 @@ __global__ __launch_bounds__(DIR_WAVES * 64) void k_dir_order(gas_group_args g, 
 #pragma unroll
 	for (int r = 0; r < DIR_ROUNDS; r++) {
 		const gas_params *P = fresh ? fresh + row[r] : params + slot[r];
-		const uint32_t d = P->hrtf_dir;
+		const uint32_t d = (GAS_DIRSORT_ABL & 1) ? (slot[r] * 2654435761u) >> 22 : P->hrtf_dir;
 		key[r] = valid[r] && d < dirs ? d : 0; // the clamp of k_hrtf_ols
 	}
 	__syncthreads();
 	uint16_t *myh = hist + (size_t)wave * dirs;
-	uint32_t rank[DIR_ROUNDS];
+	uint32_t rank[DIR_ROUNDS] = {};
 	const uint64_t lt = (1ull << lane) - 1;
 #pragma unroll
-	for (int r = 0; r < DIR_ROUNDS; r++) {
+	for (int r = 0; r < ((GAS_DIRSORT_ABL & 2) ? 0 : DIR_ROUNDS); r++) {
 		uint64_t same = __ballot(valid[r]);
 #pragma unroll
 		for (int b = 0; b < DIR_KEY_BITS; b++) {
