@@ -126,7 +126,7 @@ def main():
     ap.add_argument("--dirs", type=int, default=1024)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-max-sources", action="store_true")
-    ap.add_argument("--profile-every", type=int, default=4, help="bracket the dominant kernel of every Nth step with HIP events (markers cost ~2 us each)")
+    ap.add_argument("--profile-every", type=int, default=-1, help="bracket the dominant kernel of every Nth step with HIP events; a marked step costs ~5 us more, so the default (-1) marks about 12-16 steps of the run: N = clamp(steps // 12, 1, 16); 0 = no markers")
     ap.add_argument("--reduce-bucket", type=int, default=32, help="callbacks per cross-GPU reduce (N > 1)")
     ap.add_argument("--crossfade", action="store_true", help="GAS_FLAG_HRTF_CROSSFADE: blend old/new HRIRs when a source's direction changes (SURVEY 8f#4)")
     ap.add_argument("--no-pipelined-mix", action="store_true", help="without GAS_FLAG_PIPELINED_MIX: the partial-mix sum of callback t runs before callback t+1's DSP kernel instead of under it")
@@ -267,7 +267,8 @@ def main():
     for k in range(args.warmup):
         step(k)
     drain(args.warmup)
-    ctx.profile_enable(args.profile_every)
+    profile_every = args.profile_every if args.profile_every >= 0 else max(1, min(16, args.steps // 12))
+    ctx.profile_enable(profile_every)
     ctx.profile_read(reset=True)
     torch.cuda.synchronize()
     if world > 1:
