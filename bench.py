@@ -31,7 +31,7 @@ WORKLOADS = {
     "erhrtf": (2, (2, 3), 256, 4096, 4096, "cfg5: 4096 sources, 8-tap early reflections + HRTF chain, 256-frame @48kHz"),
 }
 HBM_PEAK = 8.0e12  # MI355X_MICROARCH.md: 8 TB/s spec
-N_SRC_BUFFERS_BYTES = 320 << 20  # rotate source buffers over > 256 MiB so the Infinity Cache cannot hold them
+N_SRC_BUFFERS_BYTES = int(os.environ.get("GAS_BENCH_SRC_BYTES", 320 << 20))  # rotate source buffers over > 256 MiB so the Infinity Cache cannot hold them (the override is a cache experiment, never the headline)
 
 
 def pmc_traffic(kernel, workload, n_local, peaks, pipelined):
@@ -132,6 +132,7 @@ def main():
     ap.add_argument("--no-pipelined-mix", action="store_true", help="without GAS_FLAG_PIPELINED_MIX: the partial-mix sum of callback t runs before callback t+1's DSP kernel instead of under it")
     ap.add_argument("--direction-order", action="store_true", help="GAS_FLAG_DIRECTION_ORDER: let the library group sources by HRIR direction (device sort per publish)")
     ap.add_argument("--presorted-directions", action="store_true", help="GAS_FLAG_DIRECTION_RUNS with parameters whose HRIR directions are grouped in callback order (what a caller that sorts its list gets)")
+    ap.add_argument("--xcd-directions", action="store_true", help="experiment: draw each source's HRIR direction from the eighth of the table that belongs to its workgroup's XCD (upper bound of an XCD-aware source partition)")
     ap.add_argument("--draining-every", type=int, default=64, help="1 source in N has ended its stream (exact peak needed, audio_spatializer.cpp:464-469); 0 = none")
     ap.add_argument("--exact-peaks", action="store_true", help="per-source inverse FFTs for every source (exact peak of every source)")
     args = ap.parse_args()
@@ -200,6 +201,9 @@ def main():
         p = synth.draw_params(prng, n_local, dirs=args.dirs, ring_frames=max(ring, 2 * frames), frames=frames)
         if args.presorted_directions:
             p["hrtf_dir"] = np.sort(p["hrtf_dir"])
+        if args.xcd_directions:
+            per_wg = max(1, n_local // 256)
+            p["hrtf_dir"] = (prng.integers(0, args.dirs // 8, n_local) * 8 + (np.arange(n_local) // per_wg) % 8).astype(np.uint32)
         psets.append(torch.from_numpy(p.view(np.uint8).reshape(n_local, 128).copy()).cuda())
     ctx.params_publish_batch(slots, synth.draw_params(prng, n_local, dirs=args.dirs, ring_frames=max(ring, 2 * frames), frames=frames))
 

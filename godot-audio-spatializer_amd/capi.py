@@ -156,6 +156,7 @@ EXPORTS = [
     "gas_mix_channel_1",
     "gas_profile_enable",
     "gas_profile_read",
+    "gas_bandwidth_probe",
 ]
 
 
@@ -225,6 +226,7 @@ def load_library():
     L.gas_mix_channel_1.argtypes = [vp, u32, i32, vp, vp, i32]
     L.gas_profile_enable.argtypes = [vp, i32]
     L.gas_profile_read.argtypes = [vp, C.POINTER(Profile), i32]
+    L.gas_bandwidth_probe.argtypes = [vp, C.c_uint64, C.c_uint64, u32, u32, u32, C.POINTER(C.c_double)]
     _lib = L
     return L
 
@@ -417,6 +419,12 @@ class SpatializerContext:
 
     def profile_enable(self, on=1):
         self._check(self.lib.gas_profile_enable(self.h, int(on)), "gas_profile_enable")
+
+    def bandwidth_probe(self, read_bytes, write_bytes, workgroups=2048, unroll=4, iters=50):
+        """Span (us) of one pure streaming launch over the given byte counts, timed like the dominant kernel."""
+        us = C.c_double()
+        self._check(self.lib.gas_bandwidth_probe(self.h, int(read_bytes), int(write_bytes), int(workgroups), int(unroll), int(iters), C.byref(us)), "gas_bandwidth_probe")
+        return us.value
 
     def profile_read(self, reset=True):
         p = Profile()

@@ -95,6 +95,9 @@ struct gas_ctx {
 	gas_params *d_upload = nullptr;
 	uint32_t *d_upload_slots = nullptr;
 
+	// plain [HRTF] group of the cached list (k_hrtf_uni): which entries need their exact peak
+	uint32_t *h_peak_bits = nullptr, *d_peak_bits = nullptr; // [(max_sources + 31) / 32], bit k = entry k of the group
+	bool uni_peak_all = false, uni_peak_any = false;
 	uint32_t *h_idx = nullptr; // pinned [2 * max_sources]: slots then rows, sorted by group
 	uint32_t *d_slots = nullptr, *d_rows = nullptr; // sorted by launch group
 	uint32_t *d_slots_rows = nullptr; // the caller's list in row order (device-side parameter publication)
@@ -156,6 +159,11 @@ struct gas_ctx {
 	gas_area_send *d_calc_areas = nullptr; // gas_calc_spatialization_areas staging (host-memory calls)
 	float *d_calc_lap = nullptr;
 	gas_audio_frame *d_calc_reverb = nullptr;
+
+	// gas_bandwidth_probe: read arena (larger than the Infinity Cache, swept in rotation) and write target
+	void *d_probe_rd = nullptr, *d_probe_wr = nullptr;
+	size_t probe_rd_bytes = 0, probe_wr_bytes = 0;
+	float *d_probe_sink = nullptr;
 
 	bool profiling = false;
 	std::vector<hipEvent_t> ev;
@@ -222,6 +230,16 @@ int group_of(int kind, const int32_t *fx, uint32_t n_fx) {
 	return G_FX_GENERIC;
 }
 
+// The plain [HRTF] chain runs in k_hrtf_uni (one uniform launch, exact peaks per source on request) unless a mode
+// only k_hrtf_ols implements is on.
+inline bool uni_ok(const gas_ctx *c) {
+	return (c->cfg.flags & (GAS_FLAG_HRTF_CROSSFADE | GAS_FLAG_DIRECTION_RUNS | GAS_FLAG_DIRECTION_ORDER)) == 0;
+}
+
+inline bool wants_peak(const gas_ctx *c, const SlotInfo &si) {
+	return si.draining || !(c->cfg.flags & GAS_FLAG_PEAKS_DRAINING_ONLY);
+}
+
 uint16_t chain_signature(const int32_t *fx, uint32_t n_fx) {
 	uint16_t sig = 0;
 	for (uint32_t j = 0; j < n_fx; j++) {
@@ -240,7 +258,7 @@ bool chain_has(uint16_t sig, int kind) {
 }
 
 // Partial mixes each launch group writes (must mirror the launchers' grids).
-void plan_partials(const Group *groups, const std::vector<ChainRange> &ranges, uint32_t *pcount) {
+void plan_partials(const Group *groups, const std::vector<ChainRange> &ranges, uint32_t *pcount, bool uni_hrtf) {
 	for (int gt = 0; gt < G_COUNT; gt++) {
 		pcount[gt] = 0;
 	}
@@ -253,6 +271,9 @@ void plan_partials(const Group *groups, const std::vector<ChainRange> &ranges, u
 		gas_hrtf_plan(groups[gt].count, groups[gt + 1].count, &p);
 		pcount[gt] = p.wgs_fd;
 		pcount[gt + 1] = p.wgs_pk;
+	}
+	if (uni_hrtf && groups[G_FX_HRTF].count && !groups[G_FX_HRTF_PK].count) {
+		pcount[G_FX_HRTF] = gas_hrtf_uni_partials(groups[G_FX_HRTF].count); // k_hrtf_uni's own grid
 	}
 	if (groups[G_FX_GENERIC].count) {
 		for (const ChainRange &r : ranges) {
@@ -330,7 +351,8 @@ int join_outputs(gas_ctx *c) {
 int run_groups(gas_ctx *c, const gas_audio_frame *d_src, const uint32_t *d_slots, const uint32_t *d_rows, const Group *groups, const std::vector<ChainRange> &ranges, uint32_t n_total, gas_audio_frame *d_out, float *d_peaks, uint32_t channel_begin, uint32_t channel_count, int force_mode, bool use_order = false, bool pipelined = false) {
 	const uint32_t F = c->cfg.frames;
 	uint32_t pcount[G_COUNT];
-	plan_partials(groups, ranges, pcount);
+	const bool uni_hrtf = groups == c->groups && uni_ok(c);
+	plan_partials(groups, ranges, pcount, uni_hrtf);
 	uint32_t p_total = 0, p_mix = 0;
 	for (int gt = 0; gt < G_COUNT; gt++) {
 		p_total += pcount[gt];
@@ -343,9 +365,7 @@ int run_groups(gas_ctx *c, const gas_audio_frame *d_src, const uint32_t *d_slots
 	// column with a workgroup and the pending callback left at most 256 partial rows (k_hrtf_ols: job_issue).
 	bool carrier = false;
 	if (groups[G_FX_HRTF].count + groups[G_FX_HRTF_PK].count > 0 && !c->fused_streams && (c->cfg.flags & GAS_FLAG_HRTF_CROSSFADE) == 0) {
-		gas_hrtf_launch_plan plan;
-		gas_hrtf_plan(groups[G_FX_HRTF].count, groups[G_FX_HRTF_PK].count, &plan);
-		carrier = (plan.wgs_fd + plan.wgs_pk) * GAS_HRTF_JOB_WAVES >= F * 2 / 4 && c->pending_mix.p_total <= 256;
+		carrier = (pcount[G_FX_HRTF] + pcount[G_FX_HRTF_PK]) * GAS_HRTF_JOB_WAVES >= F * 2 / 4 && c->pending_mix.p_total <= 256;
 	}
 	pipelined = pipelined && c->pipelined_mix && channel_count == 1 && c->cfg.channel_count == 1;
 	int rc = GAS_OK;
@@ -456,6 +476,13 @@ int run_groups(gas_ctx *c, const gas_audio_frame *d_src, const uint32_t *d_slots
 				// GAS_FLAG_DIRECTION_ORDER: direction order of the frequency-domain group, rebuilt when the
 				// callback's list or any parameter changed, else reused.  Only when directions repeat within a segment.
 				const gas_params *fresh = fd_gt == G_FX_HRTF ? c->fresh_for_launch : nullptr;
+				if (gt == G_FX_HRTF && gp.count == 0 && uni_hrtf) {
+					// the whole plain-[HRTF] group in one uniform launch (k_hrtf_uni.hip)
+					e = gas_launch_hrtf_uni(c->stream, g_fd, c->uni_peak_any && !c->uni_peak_all ? c->d_peak_bits : nullptr, c->uni_peak_all, c->st, c->tab, c->d_tw, F, c->hist_len, parts, p_off, c->fused_streams ? c->d_cursors : nullptr, c->d_fade_env, fresh, job);
+					carried_bytes = job.partials ? ((uint64_t)job.p_count + 1) * job.elems * sizeof(float) : 0;
+					job = gas_deferred_reduce();
+					break;
+				}
 				if (use_order && (c->cfg.flags & GAS_FLAG_DIRECTION_ORDER) != 0 && g_fd.n >= GAS_DIR_ORDER_MIN_SOURCES && (c->cfg.flags & GAS_FLAG_HRTF_CROSSFADE) == 0 && gas_dir_order_supported(c->tab.dirs)) {
 					const uint32_t seg = g_fd.n < GAS_DIR_ORDER_SEGMENT ? g_fd.n : GAS_DIR_ORDER_SEGMENT;
 					if (seg >= 2 * c->tab.dirs) {
@@ -615,8 +642,8 @@ int apply_pending_frees(gas_ctx *c) {
 
 // HRTF sources take the frequency-domain path unless their peak is needed.
 inline int launch_group(const gas_ctx *c, const SlotInfo &si) {
-	const bool want_peak = si.draining || !(c->cfg.flags & GAS_FLAG_PEAKS_DRAINING_ONLY);
-	if (si.group == G_FX_HRTF && want_peak) {
+	const bool want_peak = wants_peak(c, si);
+	if (si.group == G_FX_HRTF && want_peak && !uni_ok(c)) {
 		return G_FX_HRTF_PK;
 	}
 	if (si.group == G_FX_ER_HRTF && want_peak) {
@@ -696,6 +723,24 @@ int build_groups(gas_ctx *c, const uint32_t *slots, uint32_t n) {
 		}
 	}
 	c->cached_identity_rows = nonempty <= 1 && c->chain_ranges.size() <= 1;
+	c->uni_peak_all = c->uni_peak_any = false;
+	if (uni_ok(c) && c->groups[G_FX_HRTF].count > 0) {
+		const Group &gh = c->groups[G_FX_HRTF];
+		const uint32_t words = (gh.count + 31) / 32;
+		std::memset(c->h_peak_bits, 0, (size_t)words * sizeof(uint32_t));
+		uint32_t n_peak = 0;
+		for (uint32_t k = 0; k < gh.count; k++) {
+			if (wants_peak(c, c->slots[hs[gh.offset + k]])) {
+				c->h_peak_bits[k >> 5] |= 1u << (k & 31);
+				n_peak++;
+			}
+		}
+		c->uni_peak_any = n_peak > 0;
+		c->uni_peak_all = n_peak == gh.count;
+		if (c->uni_peak_any && !c->uni_peak_all) {
+			GAS_HIP(c, hipMemcpyAsync(c->d_peak_bits, c->h_peak_bits, (size_t)words * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+		}
+	}
 	if (n > 0) {
 		GAS_HIP(c, hipMemcpyAsync(c->d_slots, hs, (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
 		if (!c->cached_identity_rows) {
@@ -802,6 +847,9 @@ void gas_ctx_destroy(gas_ctx *c) {
 	for (auto &s : c->streams) {
 		(void)hipFree(s.d_pcm);
 	}
+	(void)hipFree(c->d_probe_rd);
+	(void)hipFree(c->d_probe_wr);
+	(void)hipFree(c->d_probe_sink);
 	(void)hipFree(c->d_calc_cfgs);
 	(void)hipFree(c->d_calc_listeners);
 	(void)hipFree(c->d_calc_slots);
@@ -815,6 +863,8 @@ void gas_ctx_destroy(gas_ctx *c) {
 	(void)hipHostFree(c->h_upload);
 	(void)hipHostFree(c->h_upload_slots);
 	(void)hipHostFree(c->h_idx);
+	(void)hipHostFree(c->h_peak_bits);
+	(void)hipFree(c->d_peak_bits);
 	if (c->own_stream && c->stream) {
 		(void)hipStreamDestroy(c->stream);
 	}
@@ -901,6 +951,8 @@ int gas_ctx_create(const gas_config *cfg, gas_ctx **out_ctx) {
 		GAS_HIP(c, hipHostMalloc(&c->h_upload, sizeof(gas_params) * N, hipHostMallocDefault));
 		GAS_HIP(c, hipHostMalloc(&c->h_upload_slots, sizeof(uint32_t) * N, hipHostMallocDefault));
 		GAS_HIP(c, hipHostMalloc(&c->h_idx, sizeof(uint32_t) * 2 * N, hipHostMallocDefault));
+		GAS_HIP(c, hipHostMalloc(&c->h_peak_bits, sizeof(uint32_t) * ((N + 31) / 32), hipHostMallocDefault));
+		GAS_HIP(c, hipMalloc(&c->d_peak_bits, sizeof(uint32_t) * ((N + 31) / 32)));
 		float2 h_tw[64 * 16];
 		gas_make_twiddles(h_tw);
 		GAS_HIP(c, hipMalloc(&c->d_tw, sizeof(h_tw)));
@@ -1711,6 +1763,75 @@ int gas_profile_enable(gas_ctx *c, int on) {
 	c->prof_every = on > 1 ? (uint32_t)on : 1; // on = N > 1: bracket every Nth callback only (the markers cost throughput)
 	c->prof_tick = 0;
 	return GAS_OK;
+}
+
+int gas_bandwidth_probe(gas_ctx *c, uint64_t read_bytes, uint64_t write_bytes, uint32_t workgroups, uint32_t unroll, uint32_t iters, double *out_us) {
+	if (!c || !out_us || iters == 0 || workgroups == 0 || read_bytes % 16 != 0 || write_bytes % 16 != 0 || read_bytes + write_bytes == 0) {
+		return GAS_ERR_INVALID_ARGUMENT;
+	}
+	GAS_HIP(c, hipSetDevice(c->cfg.device));
+	GAS_HIP(c, hipStreamSynchronize(c->stream));
+	// the read arena is swept in rotation so that successive launches cannot be served by the 256 MiB Infinity Cache
+	const size_t want_rd = read_bytes ? ((size_t)(320u << 20) / read_bytes + 2) * read_bytes : 16;
+	if (want_rd > c->probe_rd_bytes) {
+		(void)hipFree(c->d_probe_rd);
+		c->d_probe_rd = nullptr;
+		c->probe_rd_bytes = 0;
+		GAS_HIP(c, hipMalloc(&c->d_probe_rd, want_rd));
+		GAS_HIP(c, hipMemsetAsync(c->d_probe_rd, 0, want_rd, c->stream));
+		c->probe_rd_bytes = want_rd;
+	}
+	const size_t want_wr = write_bytes ? write_bytes : 16;
+	if (want_wr > c->probe_wr_bytes) {
+		(void)hipFree(c->d_probe_wr);
+		c->d_probe_wr = nullptr;
+		c->probe_wr_bytes = 0;
+		GAS_HIP(c, hipMalloc(&c->d_probe_wr, want_wr));
+		c->probe_wr_bytes = want_wr;
+	}
+	if (!c->d_probe_sink) {
+		GAS_HIP(c, hipMalloc(&c->d_probe_sink, 256 * sizeof(float)));
+	}
+	hipEvent_t e0 = nullptr, e1 = nullptr;
+	GAS_HIP(c, hipEventCreate(&e0));
+	GAS_HIP(c, hipEventCreate(&e1));
+	int rc = [&]() -> int {
+		// marker calibration as in gas_profile_enable: an empty bracket, minimum of 16 tries
+		double marker = 1e9;
+		for (int i = 0; i < 16; i++) {
+			GAS_HIP(c, hipEventRecord(e0, c->stream));
+			GAS_HIP(c, hipEventRecord(e1, c->stream));
+			GAS_HIP(c, hipEventSynchronize(e1));
+			float ms = 0.0f;
+			GAS_HIP(c, hipEventElapsedTime(&ms, e0, e1));
+			marker = ms < marker ? ms : marker;
+		}
+		const size_t slices = read_bytes ? c->probe_rd_bytes / read_bytes : 1;
+		size_t k = 0;
+		auto launch = [&]() {
+			const char *rd = static_cast<const char *>(c->d_probe_rd) + (k++ % slices) * read_bytes;
+			return gas_launch_stream_probe(c->stream, rd, read_bytes, c->d_probe_wr, write_bytes, workgroups, unroll, c->d_probe_sink);
+		};
+		for (int i = 0; i < 8; i++) { // warm-up, back to back
+			GAS_HIP(c, launch());
+		}
+		double sum_ms = 0.0;
+		for (uint32_t i = 0; i < iters; i++) {
+			GAS_HIP(c, launch()); // an unbracketed launch in front keeps the GPU busy, as the bench's callbacks do
+			GAS_HIP(c, hipEventRecord(e0, c->stream));
+			GAS_HIP(c, launch());
+			GAS_HIP(c, hipEventRecord(e1, c->stream));
+			GAS_HIP(c, hipEventSynchronize(e1));
+			float ms = 0.0f;
+			GAS_HIP(c, hipEventElapsedTime(&ms, e0, e1));
+			sum_ms += ms > marker ? ms - marker : 0.0;
+		}
+		*out_us = sum_ms / iters * 1e3;
+		return GAS_OK;
+	}();
+	(void)hipEventDestroy(e0);
+	(void)hipEventDestroy(e1);
+	return rc;
 }
 
 int gas_profile_read(gas_ctx *c, gas_profile *out, int reset) {

@@ -89,6 +89,10 @@ struct gas_hrtf_launch_plan {
 void gas_hrtf_plan(uint32_t n_fd, uint32_t n_pk, gas_hrtf_launch_plan *plan);
 uint32_t gas_hrtf_partials(uint32_t n); // workgroups of a single-path launch (k_er_only, k_hrtf_rows, k_rows_accumulate)
 hipError_t gas_launch_hrtf_ols(hipStream_t stream, bool with_er, bool crossfade, bool runs /* sum runs of equal directions before the FFT */, const gas_group_args &g_fd, const gas_group_args &g_pk, const gas_dev_state &st, const gas_hrtf_table &tab, const float2 *twiddles, uint32_t frames, uint32_t hist_len, uint32_t er_ring_frames, float *partials, uint32_t p_offset, gas_cursor *cursors /* non-null: sample the bound streams in the kernel */, const float *fade_env, const gas_params *fresh /* non-null: unscattered parameter rows in row order */, const gas_deferred_reduce &job = gas_deferred_reduce());
+// k_hrtf_uni.hip: all plain [HRTF] sources of a callback in one uniform launch; peak_bits (bit per group entry, or
+// nullptr) / peak_all say which sources also get their exact output peak
+uint32_t gas_hrtf_uni_partials(uint32_t n); // workgroups (= partial mixes) of a k_hrtf_uni launch
+hipError_t gas_launch_hrtf_uni(hipStream_t stream, const gas_group_args &g, const uint32_t *peak_bits, bool peak_all, const gas_dev_state &st, const gas_hrtf_table &tab, const float2 *twiddles, uint32_t frames, uint32_t hist_len, float *partials, uint32_t p_offset, gas_cursor *cursors, const float *fade_env, const gas_params *fresh, const gas_deferred_reduce &job = gas_deferred_reduce());
 hipError_t gas_launch_er_only(hipStream_t stream, const gas_group_args &g, const gas_dev_state &st, uint32_t frames, uint32_t er_ring_frames, float *partials, uint32_t p_offset, uint32_t p_stride, gas_audio_frame *rows_out = nullptr);
 // stages of a general effect chain (rows in -> rows out) and its final mix
 hipError_t gas_launch_hrtf_rows(hipStream_t stream, bool crossfade, const gas_group_args &g, const gas_dev_state &st, const gas_hrtf_table &tab, const float2 *twiddles, uint32_t frames, gas_audio_frame *rows_out);
@@ -102,6 +106,7 @@ hipError_t gas_launch_scatter_params(hipStream_t stream, gas_params *table, cons
 hipError_t gas_launch_calc_spatialization(hipStream_t stream, const gas_spatializer3d_config *cfgs, const uint32_t *cfg_index, const gas_source_pose *poses, const gas_listener *listeners, uint32_t n_listeners, const uint32_t *slots, uint32_t n, gas_params *table, uint8_t *was_further, gas_params *out_params, const gas_area_send *areas = nullptr, const float *listener_area_pos = nullptr, gas_audio_frame *out_reverb = nullptr);
 hipError_t gas_launch_sample_sources(hipStream_t stream, gas_cursor *cursors, const uint32_t *slots, uint32_t n, uint32_t frames, const float *fade_env, gas_audio_frame *rows);
 hipError_t gas_launch_noop(hipStream_t stream); // event-timer calibration
+hipError_t gas_launch_stream_probe(hipStream_t stream, const void *rd, uint64_t rd_bytes, void *wr, uint64_t wr_bytes, uint32_t workgroups, uint32_t unroll, float *sink); // copy-bandwidth ceiling
 #define GAS_DIR_ORDER_SEGMENT 8192
 #define GAS_DIR_ORDER_MIN_SOURCES 512
 bool gas_dir_order_supported(uint32_t dirs);

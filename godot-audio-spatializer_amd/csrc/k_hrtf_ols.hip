@@ -25,457 +25,9 @@
 //
 // Bound: HBM.  Algorithmic bytes/source = F*8 (source) + 2*hist_len*4 (history r+w) + 128 (params) + 8
 // (peak) + 8 (gain state), + the ring traffic (8 taps * F * 8 read + F * 8 write) with early reflections.
-#include "gas_device.h"
-#include "gas_internal.h"
+#include "gas_hrtf_wave.h"
 
 namespace {
-
-constexpr int WAVES = 8; // one workgroup = the CU's whole residency at 2 waves/SIMD -> fewest partial mixes
-#ifndef GAS_HRTF_WAVES_PER_SIMD
-#define GAS_HRTF_WAVES_PER_SIMD 2 // register budget the main kernel is compiled for (VGPR-limited residency)
-#endif
-constexpr int LDS_F2_HALF = 8 * 72; // float2 units; exchange 1 uses 8x72, exchange 2 uses 8x66
-constexpr int LDS_F2_PER_WAVE = 2 * LDS_F2_HALF; // two slices so a pair of transforms can be in flight
-constexpr float S2 = 0.70710678118654752440f;
-
-__device__ __forceinline__ float2 cadd(float2 a, float2 b) {
-	return make_float2(a.x + b.x, a.y + b.y);
-}
-__device__ __forceinline__ float2 csub(float2 a, float2 b) {
-	return make_float2(a.x - b.x, a.y - b.y);
-}
-__device__ __forceinline__ float2 cmul(float2 a, float2 b) {
-	return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
-}
-__device__ __forceinline__ float2 cmulc(float2 a, float2 b) { // a * conj(b)
-	return make_float2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y);
-}
-// Once-touched streams (source rows, history) bypass the caches' retention so they do not evict the HRIR
-// spectra table, which is the only data re-read across sources (MI355X_MICROARCH.md nt-weights row).
-#ifndef GAS_ABL
-#define GAS_ABL 0 // timing experiments only (results are wrong): 1 no table loads, 2 no history traffic, 4 no forward FFT, 8 no row loads, 16 no twiddle loads, 32 no frequency-domain epilogue, 64 no per-source state writes, 128 no parameter loads, 256 empty body (the launch's own floor)
-#endif
-#ifdef GAS_USE_NT // measured: no effect on MI355X for this kernel (profiles/r01_notes.md); kept as a switch
-#define GAS_NT_LOAD(p) __builtin_nontemporal_load(p)
-#define GAS_NT_STORE(v, p) __builtin_nontemporal_store(v, p)
-#else
-#define GAS_NT_LOAD(p) (*(p))
-#define GAS_NT_STORE(v, p) (*(p) = (v))
-#endif
-__device__ __forceinline__ gas_audio_frame nt_load_frame(const gas_audio_frame *p) {
-	typedef float v2f __attribute__((ext_vector_type(2)));
-	const v2f v = GAS_NT_LOAD(reinterpret_cast<const v2f *>(p));
-	return gas_audio_frame{ v.x, v.y };
-}
-
-// multiply by -i (forward) / +i (inverse)
-template <bool INV>
-__device__ __forceinline__ float2 rot(float2 a) {
-	return INV ? make_float2(-a.y, a.x) : make_float2(a.y, -a.x);
-}
-
-// 8-point DFT in registers (tools/fft512_prototype.py dft8).
-template <bool INV>
-__device__ __forceinline__ void dft8(float2 (&v)[8]) {
-	float2 a0 = cadd(v[0], v[4]), a1 = csub(v[0], v[4]);
-	float2 a2 = cadd(v[2], v[6]), a3 = rot<INV>(csub(v[2], v[6]));
-	float2 a4 = cadd(v[1], v[5]), a5 = csub(v[1], v[5]);
-	float2 a6 = cadd(v[3], v[7]), a7 = rot<INV>(csub(v[3], v[7]));
-	float2 b0 = cadd(a0, a2), b2 = csub(a0, a2);
-	float2 b1 = cadd(a1, a3), b3 = csub(a1, a3);
-	float2 b4 = cadd(a4, a6), b6 = rot<INV>(csub(a4, a6));
-	float2 b5 = cadd(a5, a7), b7 = csub(a5, a7);
-	if (INV) { // W8^-1 = (1+i)/sqrt2, W8^-3 = (-1+i)/sqrt2
-		b5 = make_float2(S2 * (b5.x - b5.y), S2 * (b5.x + b5.y));
-		b7 = make_float2(S2 * (-b7.x - b7.y), S2 * (b7.x - b7.y));
-	} else { // W8^1 = (1-i)/sqrt2, W8^3 = (-1-i)/sqrt2
-		b5 = make_float2(S2 * (b5.x + b5.y), S2 * (b5.y - b5.x));
-		b7 = make_float2(S2 * (b7.y - b7.x), S2 * (-b7.x - b7.y));
-	}
-	v[0] = cadd(b0, b4);
-	v[1] = cadd(b1, b5);
-	v[2] = cadd(b2, b6);
-	v[3] = cadd(b3, b7);
-	v[4] = csub(b0, b4);
-	v[5] = csub(b1, b5);
-	v[6] = csub(b2, b6);
-	v[7] = csub(b3, b7);
-}
-
-// Orders this wave's LDS traffic for the compiler; the hardware executes one wave's DS
-// instructions in order, so no wait is needed between a wave's own store and load.
-__device__ __forceinline__ void wave_lds_sync() {
-	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-	__builtin_amdgcn_wave_barrier();
-	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
-// 512-point FFT of one wave: in/out v[j] of lane l = element l + 64 j (natural order both sides).
-// t1[k0] = W64^(n1 k0) with n1 = l>>3; t2[k1] = W512^(n0 (k0' + 8 k1)) with n0 = l&7, k0' = l>>3.
-template <bool INV>
-__device__ __forceinline__ void fft512(float2 (&v)[8], const float2 (&t1)[8], const float2 (&t2)[8], float2 *lds, int lane) {
-	const int hi = lane >> 3, lo = lane & 7;
-	dft8<INV>(v);
-#pragma unroll
-	for (int k = 1; k < 8; k++) {
-		v[k] = INV ? cmulc(v[k], t1[k]) : cmul(v[k], t1[k]);
-	}
-#pragma unroll
-	for (int k = 0; k < 8; k++) {
-		lds[k * 72 + lane] = v[k];
-	}
-	wave_lds_sync();
-#pragma unroll
-	for (int k = 0; k < 8; k++) {
-		v[k] = lds[hi * 72 + k * 8 + lo];
-	}
-	wave_lds_sync();
-	dft8<INV>(v);
-#pragma unroll
-	for (int k = 0; k < 8; k++) {
-		v[k] = INV ? cmulc(v[k], t2[k]) : cmul(v[k], t2[k]);
-	}
-#pragma unroll
-	for (int k = 0; k < 8; k++) {
-		lds[lo * 66 + k * 8 + hi] = v[k];
-	}
-	wave_lds_sync();
-#pragma unroll
-	for (int k = 0; k < 8; k++) {
-		v[k] = lds[k * 66 + lane];
-	}
-	wave_lds_sync();
-	dft8<INV>(v);
-}
-
-// max over the wave of a NON-NEGATIVE value, on the VALU's DPP data path (no LDS round trips):
-// row_shr 1,2,4,8 leave each 16-lane row's max in its lane 15, row_bcast15 / row_bcast31 fold the
-// rows; zero fill is the identity for non-negative inputs.  Lane 63 holds the result.
-// Two independent 512-point FFTs of one wave, interleaved pass by pass so the LDS exchange of one
-// overlaps the butterflies of the other (lds0 / lds1 are disjoint slices).
-template <bool INV>
-__device__ __forceinline__ void fft512_pair(float2 (&a)[8], float2 (&b)[8], const float2 (&t1)[8], const float2 (&t2)[8], float2 *lds0, float2 *lds1, int lane) {
-	const int hi = lane >> 3, lo = lane & 7;
-	dft8<INV>(a);
-#pragma unroll
-	for (int k = 1; k < 8; k++) {
-		a[k] = INV ? cmulc(a[k], t1[k]) : cmul(a[k], t1[k]);
-	}
-#pragma unroll
-	for (int k = 0; k < 8; k++) {
-		lds0[k * 72 + lane] = a[k];
-	}
-	dft8<INV>(b);
-#pragma unroll
-	for (int k = 1; k < 8; k++) {
-		b[k] = INV ? cmulc(b[k], t1[k]) : cmul(b[k], t1[k]);
-	}
-#pragma unroll
-	for (int k = 0; k < 8; k++) {
-		lds1[k * 72 + lane] = b[k];
-	}
-	wave_lds_sync();
-#pragma unroll
-	for (int k = 0; k < 8; k++) {
-		a[k] = lds0[hi * 72 + k * 8 + lo];
-	}
-#pragma unroll
-	for (int k = 0; k < 8; k++) {
-		b[k] = lds1[hi * 72 + k * 8 + lo];
-	}
-	wave_lds_sync();
-	dft8<INV>(a);
-#pragma unroll
-	for (int k = 0; k < 8; k++) {
-		a[k] = INV ? cmulc(a[k], t2[k]) : cmul(a[k], t2[k]);
-	}
-#pragma unroll
-	for (int k = 0; k < 8; k++) {
-		lds0[lo * 66 + k * 8 + hi] = a[k];
-	}
-	dft8<INV>(b);
-#pragma unroll
-	for (int k = 0; k < 8; k++) {
-		b[k] = INV ? cmulc(b[k], t2[k]) : cmul(b[k], t2[k]);
-	}
-#pragma unroll
-	for (int k = 0; k < 8; k++) {
-		lds1[lo * 66 + k * 8 + hi] = b[k];
-	}
-	wave_lds_sync();
-#pragma unroll
-	for (int k = 0; k < 8; k++) {
-		a[k] = lds0[k * 66 + lane];
-	}
-#pragma unroll
-	for (int k = 0; k < 8; k++) {
-		b[k] = lds1[k * 66 + lane];
-	}
-	wave_lds_sync();
-	dft8<INV>(a);
-	dft8<INV>(b);
-}
-
-__device__ __forceinline__ float wave_max(float v) {
-	int x = __float_as_int(v);
-#define GAS_DPP_MAX(ctrl, row_mask)                                                                    \
-	x = __float_as_int(fmaxf(__int_as_float(x), __int_as_float(__builtin_amdgcn_update_dpp(0, x, ctrl, row_mask, 0xF, false))))
-	GAS_DPP_MAX(0x111, 0xF); // row_shr:1
-	GAS_DPP_MAX(0x112, 0xF); // row_shr:2
-	GAS_DPP_MAX(0x114, 0xF); // row_shr:4
-	GAS_DPP_MAX(0x118, 0xF); // row_shr:8
-	GAS_DPP_MAX(0x142, 0xA); // row_bcast:15 -> rows 1,3
-	GAS_DPP_MAX(0x143, 0xC); // row_bcast:31 -> rows 2,3
-#undef GAS_DPP_MAX
-	return __int_as_float(__builtin_amdgcn_readlane(x, 63));
-}
-
-// Wave-uniform description of one source of the callback (scalar registers).
-struct SrcMeta {
-	uint32_t slot, row, dir;
-	uint32_t pdir; // direction of the previous callback (== dir when there was none): cross-fade source (8f#4)
-	float g0, g1;
-	// device-resident stream cursor (SRC_PCM only)
-	const void *pcm;
-	uint64_t len, pos, start;
-	uint32_t fc, hf, mixed;
-};
-
-// Metadata of a wave's sources lives one-source-per-lane in VGPRs: the dependent loads
-// (slot list -> parameter table -> direction) are paid once per wave, for all of its sources in
-// parallel, instead of once per source on the critical path (dependent scalar loads share lgkmcnt
-// with the FFT's LDS exchanges and cost ~16 us per launch when done per source).
-struct LaneMeta {
-	uint32_t slot, row, dir, pdir;
-	float g0, g1;
-	gas_cursor cur;
-};
-
-__device__ __forceinline__ uint64_t readlane64(uint64_t v, int i) {
-	const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, i);
-	const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), i);
-	return ((uint64_t)hi << 32) | lo;
-}
-
-template <bool SRC_PCM>
-__device__ __forceinline__ SrcMeta bcast_meta(const LaneMeta &lm, uint32_t i, uint32_t F) {
-	SrcMeta m{};
-	m.slot = (uint32_t)__builtin_amdgcn_readlane((int)lm.slot, (int)i);
-	m.row = (uint32_t)__builtin_amdgcn_readlane((int)lm.row, (int)i);
-	m.dir = (uint32_t)__builtin_amdgcn_readlane((int)lm.dir, (int)i);
-	m.pdir = (uint32_t)__builtin_amdgcn_readlane((int)lm.pdir, (int)i);
-	m.g0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lm.g0), (int)i));
-	m.g1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lm.g1), (int)i));
-	if constexpr (SRC_PCM) {
-		m.pcm = reinterpret_cast<const void *>(readlane64(reinterpret_cast<uint64_t>(lm.cur.pcm), (int)i));
-		m.len = readlane64(lm.cur.frames, (int)i);
-		m.pos = readlane64(lm.cur.pos, (int)i);
-		m.start = readlane64(lm.cur.start, (int)i);
-		m.fc = (uint32_t)__builtin_amdgcn_readlane((int)lm.cur.format_channels, (int)i);
-		m.hf = (uint32_t)__builtin_amdgcn_readlane((int)lm.cur.has_frames, (int)i);
-		m.hf = (m.hf && m.pcm) ? 1u : 0u;
-		const uint64_t left = m.len > m.pos ? m.len - m.pos : 0;
-		m.mixed = m.hf ? (left < F ? (uint32_t)left : F) : 0; // [ENGINE] AudioStreamPlayback::mix return value
-	}
-	return m;
-}
-
-// The F frames of the source window the DSP sees (audio_spatializer.cpp:367-408), lane l taking frames l + 64 q.
-// Float rows: the caller's [n][F] buffer.  SRC_PCM: sampled here from the HBM-resident stream -- k_sample_sources'
-// logic, fused: 64-frame lookahead delay, silence in front of the playback's start, fade-out over the last 64
-// valid frames, zero feed afterwards.  The format switch sits outside the frame loop and every load is
-// unconditional (out-of-window lanes read index 0 and are masked afterwards), so the loads issue back to back.
-template <bool SRC_PCM, int FQ>
-__device__ __forceinline__ void load_window(const gas_group_args &g, const SrcMeta &m, int lane, const float *__restrict__ fade_env, gas_audio_frame (&raw)[FQ]) {
-	constexpr uint32_t F = FQ * 64;
-	if constexpr (!SRC_PCM) {
-#pragma unroll
-		for (int q = 0; q < FQ; q++) {
-			raw[q] = (GAS_ABL & 8) ? gas_audio_frame{ (float)lane, (float)m.row } : nt_load_frame(&g.src[(size_t)m.row * F + lane + 64 * q]);
-		}
-	} else {
-		const void *p = m.hf ? m.pcm : static_cast<const void *>(fade_env); // any readable address when nothing plays
-		const int64_t base = (int64_t)m.pos - GAS_LOOKAHEAD_BUFFER_SIZE;
-		bool ok[FQ];
-		int64_t idx[FQ];
-#pragma unroll
-		for (int q = 0; q < FQ; q++) {
-			const uint32_t f = (uint32_t)(lane + 64 * q);
-			const int64_t si = base + f;
-			ok[q] = m.hf && (m.mixed == F || f < m.mixed + GAS_LOOKAHEAD_BUFFER_SIZE) && si >= (int64_t)m.start;
-			idx[q] = ok[q] ? si : 0;
-		}
-		const uint32_t fmt = m.fc >> 8, ch = m.fc & 0xff;
-		if (fmt == GAS_PCM_S16 && ch == 1) {
-			short x[FQ];
-#pragma unroll
-			for (int q = 0; q < FQ; q++) {
-				x[q] = static_cast<const short *>(p)[idx[q]];
-			}
-#pragma unroll
-			for (int q = 0; q < FQ; q++) {
-				const float v = (float)x[q] / 32768.0f;
-				raw[q] = gas_audio_frame{ v, v };
-			}
-		} else if (fmt == GAS_PCM_S16) {
-			short2 x[FQ];
-#pragma unroll
-			for (int q = 0; q < FQ; q++) {
-				x[q] = static_cast<const short2 *>(p)[idx[q]];
-			}
-#pragma unroll
-			for (int q = 0; q < FQ; q++) {
-				raw[q] = gas_audio_frame{ (float)x[q].x / 32768.0f, (float)x[q].y / 32768.0f };
-			}
-		} else if (ch == 1) {
-#pragma unroll
-			for (int q = 0; q < FQ; q++) {
-				const float v = static_cast<const float *>(p)[idx[q]];
-				raw[q] = gas_audio_frame{ v, v };
-			}
-		} else {
-#pragma unroll
-			for (int q = 0; q < FQ; q++) {
-				const float2 v = static_cast<const float2 *>(p)[idx[q]];
-				raw[q] = gas_audio_frame{ v.x, v.y };
-			}
-		}
-		const bool ending = m.hf && m.mixed != F; // :380-396, once per playback
-#pragma unroll
-		for (int q = 0; q < FQ; q++) {
-			const uint32_t f = (uint32_t)(lane + 64 * q);
-			float e = ok[q] ? 1.0f : 0.0f;
-			if (ending && f >= m.mixed) {
-				e *= fade_env[(f - m.mixed) & (GAS_LOOKAHEAD_BUFFER_SIZE - 1)];
-			}
-			raw[q].left *= e;
-			raw[q].right *= e;
-		}
-	}
-}
-
-// HRIR spectra table: the HRIRs are real, so H[512-k] = conj(H[k]); only bins 0..255 are stored per
-// direction (4 KiB: float4 = HL.re, HL.im, HR.re, HR.im), with the real Nyquist bin H[256] parked in the
-// (zero) imaginary slots of DC.  Lane l needs bins l + 64 j: j < 4 come straight from the table, j >= 4
-// are fetched as bin 512 - k -- the same 4 KiB, mirrored addressing -- and conjugated.  This halves the
-// table footprint (4 MiB at 1024 directions = one XCD L2) and its L2 -> CU traffic per source.
-__device__ __forceinline__ void issue_spectra(const float4 *__restrict__ spec, uint32_t dir, int lane, float4 (&hs)[8]) {
-	if (GAS_ABL & 1) {
-#pragma unroll
-		for (int j = 0; j < 8; j++) {
-			hs[j] = make_float4(1.0f, 0.5f, 0.25f, (float)dir);
-		}
-		return;
-	}
-	const float4 *base = spec + (size_t)dir * 256;
-#pragma unroll
-	for (int j = 0; j < 4; j++) {
-		hs[j] = base[j * 64 + lane];
-	}
-#pragma unroll
-	for (int j = 4; j < 8; j++) {
-		int p = 512 - (lane + 64 * j); // 1..256
-		p = p == 256 ? 0 : p; // lane 0, j = 4: the Nyquist bin lives in DC's imaginary slots
-		hs[j] = base[p];
-	}
-}
-
-// Turns the registers filled by issue_spectra into H[lane + 64 j] for every j.
-__device__ __forceinline__ void finish_spectra(int lane, float4 (&hs)[8]) {
-#pragma unroll
-	for (int j = 4; j < 8; j++) {
-		hs[j].y = -hs[j].y;
-		hs[j].w = -hs[j].w;
-	}
-	if (lane == 0) {
-		hs[4] = make_float4(hs[0].y, 0.0f, hs[0].w, 0.0f);
-		hs[0].y = 0.0f;
-		hs[0].w = 0.0f;
-	}
-}
-
-// The previous callback's k_mix_reduce, done by one wave of this workgroup for float4 column `col` (one column per
-// job wave; the context only hands a job over when the grid covers every column and p_count <= 256).  The four
-// partial rows a lane sums are loaded at kernel start and parked in registers, so the sum itself -- gas_device.h's
-// column sum, the very code k_mix_reduce runs, hence the same bits -- finds them landed and hides behind the other
-// waves' epilogue.
-constexpr int JOB_ROWS = 4; // rows lane, lane + 64, lane + 128, lane + 192
-__device__ __forceinline__ void job_issue(const gas_deferred_reduce &j, uint32_t col, int lane, float4 (&jr)[JOB_ROWS]) {
-	const uint32_t e4 = j.elems / 4;
-	const float4 *p = reinterpret_cast<const float4 *>(j.partials) + col;
-#pragma unroll
-	for (int r = 0; r < JOB_ROWS; r++) {
-		const uint32_t k = (uint32_t)lane + 64u * r;
-		const float4 v = p[(size_t)(k < j.p_count ? k : 0) * e4];
-		const float keep = k < j.p_count ? 1.0f : 0.0f; // missing rows contribute +0: x + 0 = x changes no bit
-		jr[r] = make_float4(keep != 0.0f ? v.x : 0.0f, keep != 0.0f ? v.y : 0.0f, keep != 0.0f ? v.z : 0.0f, keep != 0.0f ? v.w : 0.0f);
-	}
-}
-
-__device__ __forceinline__ void job_finish(const gas_deferred_reduce &j, uint32_t col, int lane, const float4 (&jr)[JOB_ROWS]) {
-	float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-	for (int r = 0; r < JOB_ROWS; r++) {
-		gas_mix_column_add(s, jr[r]);
-	}
-	const float4 t = gas_mix_column_fold(s);
-	if (lane == 0) {
-		reinterpret_cast<float4 *>(j.out)[col] = t;
-	}
-}
-
-// Sources [first, last) of wave `gw` out of `n_waves`: an even split (the first n % n_waves waves take one more), so
-// every planned workgroup has work.
-__device__ __forceinline__ void wave_range(uint32_t n, uint32_t gw, uint32_t n_waves, uint32_t &first, uint32_t &last) {
-	const uint32_t base = n / n_waves, rem = n % n_waves;
-	first = gw * base + (gw < rem ? gw : rem);
-	last = first + base + (gw < rem ? 1u : 0u);
-}
-
-// History rows are stored lane-major -- element lane * HQ + q holds x[lane + 64 q] -- so a lane's HQ samples are one
-// contiguous 4*HQ-byte piece (one 16-byte access at F = 512 instead of four 4-byte ones: the history cost 3.1 us of
-// the 16.7 us kernel as 4-byte accesses).  The layout is private to this file; k_zero_slot only writes zeros.
-template <int HQ>
-__device__ __forceinline__ void load_history(const float *__restrict__ row, int lane, float (&h)[HQ]) {
-	if constexpr (HQ % 4 == 0) {
-#pragma unroll
-		for (int q = 0; q < HQ; q += 4) {
-			const float4 v = *reinterpret_cast<const float4 *>(row + lane * HQ + q);
-			h[q] = v.x; h[q + 1] = v.y; h[q + 2] = v.z; h[q + 3] = v.w;
-		}
-	} else if constexpr (HQ % 2 == 0) {
-#pragma unroll
-		for (int q = 0; q < HQ; q += 2) {
-			const float2 v = *reinterpret_cast<const float2 *>(row + lane * HQ + q);
-			h[q] = v.x; h[q + 1] = v.y;
-		}
-	} else {
-#pragma unroll
-		for (int q = 0; q < HQ; q++) {
-			h[q] = row[lane * HQ + q];
-		}
-	}
-}
-
-template <int HQ>
-__device__ __forceinline__ void store_history(float *__restrict__ row, int lane, const float *h) {
-	if constexpr (HQ % 4 == 0) {
-#pragma unroll
-		for (int q = 0; q < HQ; q += 4) {
-			*reinterpret_cast<float4 *>(row + lane * HQ + q) = make_float4(h[q], h[q + 1], h[q + 2], h[q + 3]);
-		}
-	} else if constexpr (HQ % 2 == 0) {
-#pragma unroll
-		for (int q = 0; q < HQ; q += 2) {
-			*reinterpret_cast<float2 *>(row + lane * HQ + q) = make_float2(h[q], h[q + 1]);
-		}
-	} else {
-#pragma unroll
-		for (int q = 0; q < HQ; q++) {
-			row[lane * HQ + q] = h[q];
-		}
-	}
-}
 
 // SQ = S/64 = F/128: 4 for F = 512, 2 for F = 256.
 //
@@ -499,7 +51,7 @@ struct HrtfLds {
 };
 
 template <int SQ, bool WITH_ER, bool PEAKS, bool SRC_PCM, bool XFADE, bool RUNS = false>
-__device__ __forceinline__ void hrtf_body(float2 *lds_all, const uint32_t wg, const gas_group_args &g, const gas_dev_state &st, const gas_hrtf_table &tab, const float2 *__restrict__ tw, uint32_t n_wgs, uint32_t er_R, float *__restrict__ my_partial, gas_cursor *__restrict__ cursors, const float *__restrict__ fade_env, const gas_params *__restrict__ fresh, gas_audio_frame *__restrict__ rows_out = nullptr, const gas_deferred_reduce job = gas_deferred_reduce(), uint32_t job_col = 0) {
+__device__ __forceinline__ void hrtf_body(float2 *lds_all, float2 *tw_lds, const uint32_t wg, const gas_group_args &g, const gas_dev_state &st, const gas_hrtf_table &tab, const float2 *__restrict__ tw, uint32_t n_wgs, uint32_t er_R, float *__restrict__ my_partial, gas_cursor *__restrict__ cursors, const float *__restrict__ fade_env, const gas_params *__restrict__ fresh, gas_audio_frame *__restrict__ rows_out = nullptr, const gas_deferred_reduce job = gas_deferred_reduce(), uint32_t job_col = 0) {
 	static_assert(!(WITH_ER && SRC_PCM), "the early-reflection prologue reads float rows");
 	constexpr int FQ = 2 * SQ; // F / 64
 	constexpr int HQ = 8 - SQ; // hist_len / 64
@@ -513,11 +65,24 @@ __device__ __forceinline__ void hrtf_body(float2 *lds_all, const uint32_t wg, co
 	const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 	float2 *lds = lds_all + wave * LDS_F2_PER_WAVE;
 
+	GAS_STAMP(0);
+#ifdef GAS_STAMPS
+	asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // diagnostic: the kernel arguments have arrived
+	GAS_STAMP(6);
+#endif
+	// twiddles: the workgroup's 512 threads fetch the 8 KiB table once (16 bytes each) and park it in LDS; the
+	// per-wave register copies are filled from there after the first barrier (below, behind the metadata loads)
+	float4 tw_in = make_float4(0.f, 0.f, 0.f, 0.f);
+	if (GAS_TW_LDS && !(GAS_ABL & 16)) {
+		tw_in = reinterpret_cast<const float4 *>(tw)[threadIdx.x];
+	}
 	float2 t1[8], t2[8];
+	if (!GAS_TW_LDS || (GAS_ABL & 16)) {
 #pragma unroll
-	for (int k = 0; k < 8; k++) {
-		t1[k] = (GAS_ABL & 16) ? make_float2(0.001f * (float)(lane + k), 1.0f) : tw[k * 64 + lane];
-		t2[k] = (GAS_ABL & 16) ? make_float2(1.0f, 0.002f * (float)(lane - k)) : tw[(8 + k) * 64 + lane];
+		for (int k = 0; k < 8; k++) {
+			t1[k] = (GAS_ABL & 16) ? make_float2(0.001f * (float)(lane + k), 1.0f) : tw[k * 64 + lane];
+			t2[k] = (GAS_ABL & 16) ? make_float2(1.0f, 0.002f * (float)(lane - k)) : tw[(8 + k) * 64 + lane];
+		}
 	}
 
 	// GAS_FLAG_PIPELINED_MIX: one wave also sums the previous callback's partial mixes for one output column
@@ -603,11 +168,15 @@ __device__ __forceinline__ void hrtf_body(float2 *lds_all, const uint32_t wg, co
 		lm.slot = g.slots ? g.slots[e] : g.slot_base + e;
 		lm.row = g.rows ? g.rows[e] : e;
 	}
+#ifdef GAS_STAMPS
+	asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // diagnostic: slot / row lists (and everything issued before) have arrived
+	GAS_STAMP(7);
+#endif
 	if (have) {
 		// `fresh`: parameter rows published from device memory for exactly this callback's list (row order) and not
 		// yet scattered: consume them here and write them through to the slot table (saves the scatter launch).
 		const gas_params *P = fresh ? fresh + lm.row : st.params + lm.slot;
-		if (fresh && !(GAS_ABL & 128)) {
+		if (fresh && !GAS_DEFER_WT && !(GAS_ABL & 128)) {
 			const float4 *src4 = reinterpret_cast<const float4 *>(P);
 			float4 *dst4 = reinterpret_cast<float4 *>(st.params + lm.slot);
 #pragma unroll
@@ -667,6 +236,17 @@ __device__ __forceinline__ void hrtf_body(float2 *lds_all, const uint32_t wg, co
 			issue_spectra(tab.spec, (uint32_t)__builtin_amdgcn_readlane((int)lm.dir, 0), lane, hs);
 		}
 	}
+
+	if (GAS_TW_LDS && !(GAS_ABL & 16)) {
+		reinterpret_cast<float4 *>(tw_lds)[threadIdx.x] = tw_in;
+		__syncthreads();
+#pragma unroll
+		for (int k = 0; k < 8; k++) {
+			t1[k] = tw_lds[k * 64 + lane];
+			t2[k] = tw_lds[(8 + k) * 64 + lane];
+		}
+	}
+	GAS_STAMP(1);
 
 	// STAGES sources per trip, each with its own landing registers: while source e transforms, the frames and
 	// history of sources e+1 .. e+STAGES are in flight.
@@ -736,6 +316,11 @@ __device__ __forceinline__ void hrtf_body(float2 *lds_all, const uint32_t wg, co
 				xq[HQ + q] = mono * (m.g1 * t + (1 - t) * m.g0);
 			}
 		}
+#ifdef GAS_STAMPS
+		if (e == first) {
+			GAS_STAMP(2); // the first source's frames, history and parameters have arrived
+		}
+#endif
 		// new history = x_full[F .. F + HL)
 		if (!(GAS_ABL & 2)) {
 			store_history<HQ>(st.hrtf_hist + (size_t)m.slot * HL, lane, &xq[FQ]);
@@ -904,6 +489,17 @@ __device__ __forceinline__ void hrtf_body(float2 *lds_all, const uint32_t wg, co
 		}
 	}
 
+	GAS_STAMP(3);
+	if (GAS_DEFER_WT && have && fresh && !(GAS_ABL & 128)) {
+		// the device-published rows this launch consumed go through to the slot table here, off the path to the first
+		// transform (128 bytes per source, one lane each: 64 different cache lines per instruction)
+		const float4 *src4 = reinterpret_cast<const float4 *>(fresh + lm.row);
+		float4 *dst4 = reinterpret_cast<float4 *>(st.params + lm.slot);
+#pragma unroll
+		for (int k = 0; k < 8; k++) {
+			dst4[k] = src4[k];
+		}
+	}
 	if constexpr (SKEW) {
 		if (have_prev) { // the last run's products
 			finish_spectra(lane, hs);
@@ -965,8 +561,11 @@ __device__ __forceinline__ void hrtf_body(float2 *lds_all, const uint32_t wg, co
 				fd[(wave * 2 + 1) * 512 + j * 64 + lane] = round == 0 ? aYR[j] : bYR[j];
 			}
 			__syncthreads();
-			// every wave folds one eighth of the bins over the WAVES spectra (fixed order), into slot 0
-			{
+			if (round == 0) {
+				GAS_STAMP(4);
+			}
+			if (!GAS_EPI_DIRECT) {
+				// every wave folds one eighth of the bins over the WAVES spectra (fixed order), into slot 0
 				constexpr int PER_THREAD = 2 * 512 / (WAVES * 64); // 2 ears x 512 bins over the workgroup
 #pragma unroll
 				for (int r = 0; r < PER_THREAD; r++) {
@@ -978,8 +577,8 @@ __device__ __forceinline__ void hrtf_body(float2 *lds_all, const uint32_t wg, co
 					}
 					fd[idx] = sacc; // only this thread touches column idx: no hazard
 				}
+				__syncthreads();
 			}
-			__syncthreads();
 			if constexpr (JOB_OK) {
 				if (job_mine && round == 0) { // waves 2.. idle while 0 and 1 transform: the previous callback's sum
 					job_finish(job, job_col, lane, jr);
@@ -987,9 +586,25 @@ __device__ __forceinline__ void hrtf_body(float2 *lds_all, const uint32_t wg, co
 			}
 			if (wave < 2) {
 				float2 y[8];
+				if (GAS_EPI_DIRECT) {
+					// wave `ear` adds the WAVES spectra of its ear itself, in wave order (the same association as the
+					// fold above: ((w0 + w1) + w2) + ...), 64 conflict-free 8-byte reads per lane
 #pragma unroll
-				for (int j = 0; j < 8; j++) {
-					y[j] = fd[wave * 512 + j * 64 + lane];
+					for (int j = 0; j < 8; j++) {
+						y[j] = fd[wave * 512 + j * 64 + lane];
+					}
+#pragma unroll
+					for (int w = 1; w < WAVES; w++) {
+#pragma unroll
+						for (int j = 0; j < 8; j++) {
+							y[j] = cadd(y[j], fd[(w * 2 + wave) * 512 + j * 64 + lane]);
+						}
+					}
+				} else {
+#pragma unroll
+					for (int j = 0; j < 8; j++) {
+						y[j] = fd[wave * 512 + j * 64 + lane];
+					}
 				}
 				fft512<true>(y, t1, t2, lds_all + FD_F2 + wave * LDS_F2_HALF, lane);
 #pragma unroll
@@ -1015,6 +630,7 @@ __device__ __forceinline__ void hrtf_body(float2 *lds_all, const uint32_t wg, co
 		for (int idx = threadIdx.x; idx < (int)(F * 2); idx += WAVES * 64) {
 			my_partial[idx] = outp[idx];
 		}
+		GAS_STAMP(5);
 	}
 	(void)accL;
 	(void)accR;
@@ -1035,14 +651,15 @@ template <int SQ, bool WITH_ER, bool SRC_PCM, bool XFADE, bool RUNS>
 __global__ __launch_bounds__(WAVES * 64, GAS_HRTF_WAVES_PER_SIMD) void k_hrtf_ols(gas_group_args g_fd, gas_group_args g_pk, uint32_t wgs_fd, gas_dev_state st, gas_hrtf_table tab, const float2 *__restrict__ tw, uint32_t er_R, float *__restrict__ partials, uint32_t p_offset, gas_cursor *__restrict__ cursors, const float *__restrict__ fade_env, const gas_params *__restrict__ fresh, gas_deferred_reduce job) {
 	constexpr int LDS_F2 = HrtfLds<SQ, false>::TOTAL_F2 > HrtfLds<SQ, true>::TOTAL_F2 ? HrtfLds<SQ, false>::TOTAL_F2 : HrtfLds<SQ, true>::TOTAL_F2;
 	__shared__ float2 lds_all[LDS_F2];
+	__shared__ float2 tw_lds[GAS_TW_LDS ? 1024 : 1];
 	if ((GAS_ABL & 256) && wgs_fd != 0xffffffffu) {
 		return;
 	}
 	float *my_partial = partials + ((size_t)p_offset + blockIdx.x) * (size_t)(2 * SQ * 64 * 2);
 	if (blockIdx.x < wgs_fd) {
-		hrtf_body<SQ, WITH_ER, false, SRC_PCM, XFADE, RUNS>(lds_all, blockIdx.x, g_fd, st, tab, tw, wgs_fd, er_R, my_partial, cursors, fade_env, fresh, nullptr, job, blockIdx.x);
+		hrtf_body<SQ, WITH_ER, false, SRC_PCM, XFADE, RUNS>(lds_all, tw_lds, blockIdx.x, g_fd, st, tab, tw, wgs_fd, er_R, my_partial, cursors, fade_env, fresh, nullptr, job, blockIdx.x);
 	} else {
-		hrtf_body<SQ, WITH_ER, true, SRC_PCM, XFADE>(lds_all, blockIdx.x - wgs_fd, g_pk, st, tab, tw, gridDim.x - wgs_fd, er_R, my_partial, cursors, fade_env, fresh, nullptr, job, blockIdx.x);
+		hrtf_body<SQ, WITH_ER, true, SRC_PCM, XFADE>(lds_all, tw_lds, blockIdx.x - wgs_fd, g_pk, st, tab, tw, gridDim.x - wgs_fd, er_R, my_partial, cursors, fade_env, fresh, nullptr, job, blockIdx.x);
 	}
 }
 
@@ -1050,7 +667,8 @@ __global__ __launch_bounds__(WAVES * 64, GAS_HRTF_WAVES_PER_SIMD) void k_hrtf_ol
 template <int SQ, bool XFADE>
 __global__ __launch_bounds__(WAVES * 64, GAS_HRTF_WAVES_PER_SIMD) void k_hrtf_rows(gas_group_args g, gas_dev_state st, gas_hrtf_table tab, const float2 *__restrict__ tw, gas_audio_frame *__restrict__ rows_out) {
 	__shared__ float2 lds_all[HrtfLds<SQ, true>::TOTAL_F2];
-	hrtf_body<SQ, false, true, false, XFADE>(lds_all, blockIdx.x, g, st, tab, tw, gridDim.x, 0, nullptr, nullptr, nullptr, nullptr, rows_out);
+	__shared__ float2 tw_lds[GAS_TW_LDS ? 1024 : 1];
+	hrtf_body<SQ, false, true, false, XFADE>(lds_all, tw_lds, blockIdx.x, g, st, tab, tw, gridDim.x, 0, nullptr, nullptr, nullptr, nullptr, rows_out);
 }
 
 // The last stage of a general chain left per-source rows: add them into this workgroup's partial mix and take each
@@ -1402,3 +1020,4 @@ hipError_t gas_launch_hrtf_table(hipStream_t stream, const float *d_hrir, uint32
 	hipLaunchKernelGGL(k_hrtf_table, dim3(dirs * 2), dim3(64), 0, stream, d_hrir, dirs, taps, twiddles, spec);
 	return hipGetLastError();
 }
+

@@ -1,0 +1,442 @@
+// k_hrtf_uni.hip -- every plain [HRTF] playback of a callback in ONE uniform launch: per-source 256-tap HRIR
+// convolution by overlap-save FFT, summed over sources in the frequency domain, with exact per-source peaks for the
+// playbacks that need one.
+//
+// NEW arithmetic (the reference has no HRTF/FFT/convolution); it sits where
+// AudioSpatializerInstanceEffect::process_frames runs its effect chain (audio_spatializer_effect.cpp:52-76) and
+// feeds the accumulate + per-source peak of _mix_from_playback_list (audio_spatializer.cpp:449-461).  Semantics are
+// fixed by oracle/gas_oracle.c (fx_hrtf):
+//   x   = ((src.l + src.r) * 0.5) * (g1*t + (1-t)*g0),  t = i/F          (gain ramp as audio_spatializer_3d.cpp:591-592)
+//   out = (hrir[dir][L] * x, hrir[dir][R] * x)  over  hist ++ x           (256 taps, direction switches per block)
+//
+// How it differs from k_hrtf_ols (which keeps the early-reflection, cross-fade, direction-run and rows-out forms):
+//   * one kind of workgroup.  k_hrtf_ols splits a callback into frequency-domain workgroups and exact-peak
+//     workgroups with their own slot lists; here every source is accumulated in the frequency domain (one forward
+//     FFT-512, sum_s Z_s H[d_s], one inverse pair per workgroup) and a source whose peak the host will read (stream
+//     ended, audio_spatializer.cpp:464-469; or every source without GAS_FLAG_PEAKS_DRAINING_ONLY) additionally gets
+//     its own inverse pair, for the peak only.  Draining playbacks therefore neither re-sort the list nor skew the
+//     split of sources over waves (measured with stamps: the 5-vs-4 sources per wave of the split lists set the
+//     kernel's end 2 us after its median workgroup).
+//   * a short prologue.  With the callback's slots a contiguous range in row order nothing has to be fetched before
+//     the first source's frames and history are requested: one round trip to the first transform instead of three
+//     (kernel arguments -> slot list -> parameter row -> frames; measured 3.6 us to the first transform of 16 us).
+//     Per-source state stores, the write-through of device-published parameter rows and the loads of the carried
+//     partial-mix sum (GAS_FLAG_PIPELINED_MIX) are issued behind the source loop, off that path.
+//
+// Mapping (CDNA4, wave64), algorithm, LDS layout: gas_hrtf_wave.h / DESIGN.md 3.1.  Bound: HBM.  Algorithmic bytes
+// per source = F*8 (frames) + 2*hist_len*4 (history r+w) + 24 (gain, direction, previous gain r/w, peak).
+#include "gas_hrtf_wave.h"
+
+namespace {
+
+#ifdef GAS_STAMPS
+#define GAS_UNI_STAMP(i)                                                                                       \
+	do {                                                                                                        \
+		if (lane == 0 && (blockIdx.x * UW + wave) < 8192) {                                                     \
+			gas_stamps[(blockIdx.x * UW + wave) * GAS_STAMP_SLOTS + (i)] = __builtin_amdgcn_s_memrealtime();    \
+		}                                                                                                       \
+	} while (0)
+#else
+#define GAS_UNI_STAMP(i) do { } while (0)
+#endif
+
+// UW = waves per workgroup (one workgroup per CU).  LEAN = register diet for a third wave per SIMD (<= 168 VGPRs):
+// twiddles read from LDS at their point of use, no product skew (the table row is requested before the transform
+// and used right after it), exact peaks by two inverse transforms in sequence through one exchange slice.
+#ifndef GAS_UNI_WAVES
+#define GAS_UNI_WAVES 8
+#endif
+constexpr int UW = GAS_UNI_WAVES;
+constexpr bool LEAN = UW > 8;
+constexpr int UNI_SLICES = LEAN ? 1 : 2; // exchange slices per wave in the source loop
+
+// LDS (float2 units).  !LEAN: the source loop's exchange slices and the epilogue's fd[wave][ear][512] + two slices
+// + output alias each other.  LEAN: fd IS the running sum of every wave (its spectra accumulators live in LDS, not
+// in 32 VGPRs), so it sits in front and the exchange slices behind it; the epilogue reuses the slices.
+template <int SQ>
+struct UniLds {
+	static constexpr int F = 2 * SQ * 64;
+	static constexpr int FD_F2 = UW * 2 * 512; // fd[wave][ear][512]
+	static constexpr int EPI_F2 = FD_F2 + 2 * LDS_F2_HALF + F; // + two exchange slices + the [F][2] output
+	static constexpr int LOOP_F2 = (LEAN ? FD_F2 : 0) + UW * UNI_SLICES * LDS_F2_HALF; // source loop: exchange slices per wave
+	static constexpr int TOTAL_F2 = EPI_F2 > LOOP_F2 ? EPI_F2 : LOOP_F2;
+};
+
+template <int SQ, bool SRC_PCM>
+__global__ __launch_bounds__(UW * 64, LEAN ? 3 : GAS_HRTF_WAVES_PER_SIMD) void k_hrtf_uni(gas_group_args g, const uint32_t *__restrict__ peak_bits, uint32_t peak_all, gas_dev_state st, gas_hrtf_table tab, const float2 *__restrict__ tw, float *__restrict__ partials, uint32_t p_offset, gas_cursor *__restrict__ cursors, const float *__restrict__ fade_env, const gas_params *__restrict__ fresh, gas_deferred_reduce job) {
+	constexpr int FQ = 2 * SQ; // F / 64
+	constexpr int HQ = 8 - SQ; // hist_len / 64
+	constexpr int NQ = 8 + SQ; // (hist_len + F) / 64
+	constexpr uint32_t F = FQ * 64;
+	constexpr uint32_t HL = HQ * 64;
+	constexpr int FD_F2 = UniLds<SQ>::FD_F2;
+	__shared__ float2 lds_all[UniLds<SQ>::TOTAL_F2];
+	__shared__ float2 tw_lds[1024];
+	const int lane = threadIdx.x & 63;
+	const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+	float2 *lds = lds_all + (LEAN ? FD_F2 : 0) + wave * (UNI_SLICES * LDS_F2_HALF);
+	float2 *acc = lds_all + wave * 2 * 512; // LEAN: this wave's fd rows (left ear, then right)
+	float *my_partial = partials + ((size_t)p_offset + blockIdx.x) * (size_t)(F * 2);
+	GAS_UNI_STAMP(0);
+
+	// ---- prologue: nothing in front of the first source's frames that they do not depend on -------------------
+	constexpr int TW_PER = (512 + UW * 64 - 1) / (UW * 64); // 16-byte pieces of the 8 KiB twiddle table per thread
+	float4 tw_in[TW_PER];
+#pragma unroll
+	for (int r = 0; r < TW_PER; r++) {
+		tw_in[r] = reinterpret_cast<const float4 *>(tw)[(threadIdx.x + r * UW * 64) & 511];
+	}
+	uint32_t first, last;
+	wave_range(g.n, blockIdx.x * UW + wave, gridDim.x * UW, first, last);
+	const bool have = first + lane < last; // <= 64 sources per wave (gas_hrtf_plan): one metadata lane per source
+	LaneMeta lm{};
+	if (have) {
+		const uint32_t e = first + lane;
+		lm.slot = g.slots ? g.slots[e] : g.slot_base + e; // a contiguous slot range in row order needs no list at all
+		lm.row = g.rows ? g.rows[e] : e;
+	}
+	gas_audio_frame raw[FQ]; // frames lane + 64 q of the source in flight
+	float rawh[HQ]; // its history samples (lane-major rows: one 16-byte access per lane at F = 512)
+	if (first < last) { // wave-uniform
+		SrcMeta m0{};
+		m0.slot = (uint32_t)__builtin_amdgcn_readlane((int)lm.slot, 0);
+		m0.row = (uint32_t)__builtin_amdgcn_readlane((int)lm.row, 0);
+		load_history<HQ>(st.hrtf_hist + (size_t)m0.slot * HL, lane, rawh);
+		if constexpr (!SRC_PCM) {
+			load_window<false, FQ>(g, m0, lane, fade_env, raw);
+		}
+	}
+	uint32_t my_flag = 0; // this lane's source needs its exact peak
+	if (have) {
+		const gas_params *P = fresh ? fresh + lm.row : st.params + lm.slot;
+		const float2 gd = *reinterpret_cast<const float2 *>(&P->hrtf_gain); // hrtf_gain, hrtf_dir: one 8-byte load
+		lm.g0 = st.hrtf_prev_gain[lm.slot];
+		lm.g1 = gd.x;
+		const uint32_t d = __float_as_uint(gd.y);
+		lm.dir = d < tab.dirs ? d : 0;
+		lm.pdir = lm.dir;
+		if constexpr (SRC_PCM) {
+			lm.cur = cursors[lm.slot];
+		}
+		const uint32_t e = first + lane;
+		my_flag = peak_all ? 1u : (peak_bits ? (peak_bits[e >> 5] >> (e & 31)) & 1u : 0u);
+	}
+	if constexpr (SRC_PCM) {
+		if (first < last) {
+			load_window<true, FQ>(g, bcast_meta<true>(lm, 0, F), lane, fade_env, raw); // needs the cursor
+		}
+	}
+#pragma unroll
+	for (int r = 0; r < TW_PER; r++) {
+		if (threadIdx.x + r * UW * 64 < 512) {
+			reinterpret_cast<float4 *>(tw_lds)[threadIdx.x + r * UW * 64] = tw_in[r];
+		}
+	}
+	__syncthreads();
+	float2 t1[8], t2[8];
+	if constexpr (!LEAN) {
+#pragma unroll
+		for (int k = 0; k < 8; k++) {
+			t1[k] = tw_lds[k * 64 + lane];
+			t2[k] = tw_lds[(8 + k) * 64 + lane];
+		}
+	}
+	auto fwd = [&](float2(&v)[8], float2 *slice) {
+		if constexpr (LEAN) {
+			fft512_twlds<false>(v, tw_lds, slice, lane);
+		} else {
+			fft512<false>(v, t1, t2, slice, lane);
+		}
+	};
+	auto inv = [&](float2(&v)[8], float2 *slice) {
+		if constexpr (LEAN) {
+			fft512_twlds<true>(v, tw_lds, slice, lane);
+		} else {
+			fft512<true>(v, t1, t2, slice, lane);
+		}
+	};
+	GAS_UNI_STAMP(1);
+
+	// ---- source loop: one forward FFT per source; its spectral products are taken one transform later (the HRIR
+	// row can only be requested once the direction is known, and travels while the next source is transformed) ----
+	float2 aYL[8], aYR[8]; // sum_s Z_s H_L[d_s], sum_s Z_s H_R[d_s] of this wave's sources
+	float2 zp[8]; // spectrum of the previous source, its table row (hs) in flight
+	float4 hs[8];
+#pragma unroll
+	for (int j = 0; j < 8; j++) {
+		aYL[j] = make_float2(0.0f, 0.0f);
+		aYR[j] = make_float2(0.0f, 0.0f);
+		zp[j] = make_float2(0.0f, 0.0f);
+	}
+	bool have_prev = false; // wave-uniform
+	uint32_t prev_flag = 0, prev_row = 0;
+	if constexpr (LEAN) {
+#pragma unroll
+		for (int j = 0; j < 8; j++) {
+			acc[j * 64 + lane] = make_float2(0.0f, 0.0f);
+			acc[512 + j * 64 + lane] = make_float2(0.0f, 0.0f);
+		}
+	}
+
+	// LEAN: the products of a source right after its transform (its row was requested before the transform)
+	auto products_now = [&](const float2(&z)[8], uint32_t flag, uint32_t row) {
+		finish_spectra(lane, hs);
+		if (!flag) { // wave-uniform
+#pragma unroll
+			for (int j = 0; j < 8; j++) {
+				acc[j * 64 + lane] = cadd(acc[j * 64 + lane], cmul(z[j], make_float2(hs[j].x, hs[j].y)));
+				acc[512 + j * 64 + lane] = cadd(acc[512 + j * 64 + lane], cmul(z[j], make_float2(hs[j].z, hs[j].w)));
+			}
+			return;
+		}
+		// exact peak: one ear after the other through the wave's single exchange slice
+		float2 y[8];
+		float pk[2];
+#pragma unroll
+		for (int ear = 0; ear < 2; ear++) {
+#pragma unroll
+			for (int j = 0; j < 8; j++) {
+				y[j] = cmul(z[j], ear == 0 ? make_float2(hs[j].x, hs[j].y) : make_float2(hs[j].z, hs[j].w));
+				acc[ear * 512 + j * 64 + lane] = cadd(acc[ear * 512 + j * 64 + lane], y[j]);
+			}
+			inv(y, lds);
+			float p = 0.0f;
+#pragma unroll
+			for (int t = 0; t < SQ; t++) {
+				p = fmaxf(p, fmaxf(fabsf(y[HQ + t].x), fabsf(y[HQ + t].y)));
+			}
+			pk[ear] = wave_max(p);
+		}
+		if (lane == 0) {
+			g.peaks[(size_t)row * 2] = pk[0];
+			g.peaks[(size_t)row * 2 + 1] = pk[1];
+		}
+	};
+
+	// products of the previous source (zp x hs), its exact peak if asked for, then the request for `next_dir`'s row
+	auto products = [&](bool more, uint32_t next_dir) {
+		float2 yl[8], yr[8];
+		if (have_prev) {
+			finish_spectra(lane, hs);
+#pragma unroll
+			for (int j = 0; j < 8; j++) {
+				yl[j] = cmul(zp[j], make_float2(hs[j].x, hs[j].y));
+				yr[j] = cmul(zp[j], make_float2(hs[j].z, hs[j].w));
+				aYL[j] = cadd(aYL[j], yl[j]);
+				aYR[j] = cadd(aYR[j], yr[j]);
+			}
+		}
+		if (more) {
+			issue_spectra(tab.spec, next_dir, lane, hs);
+		}
+		if (have_prev && prev_flag) { // wave-uniform: this source's own output, for max |L|, max |R| (:436-443)
+			if constexpr (!LEAN) {
+				fft512_pair<true>(yl, yr, t1, t2, lds, lds + LDS_F2_HALF, lane);
+			}
+			float pkl = 0.0f, pkr = 0.0f;
+#pragma unroll
+			for (int t = 0; t < SQ; t++) { // valid outputs are window positions [512 - S, 512): registers j >= HQ
+				pkl = fmaxf(pkl, fmaxf(fabsf(yl[HQ + t].x), fabsf(yl[HQ + t].y)));
+				pkr = fmaxf(pkr, fmaxf(fabsf(yr[HQ + t].x), fabsf(yr[HQ + t].y)));
+			}
+			pkl = wave_max(pkl);
+			pkr = wave_max(pkr);
+			if (lane == 0) {
+				g.peaks[(size_t)prev_row * 2] = pkl;
+				g.peaks[(size_t)prev_row * 2 + 1] = pkr;
+			}
+		}
+	};
+
+	for (uint32_t e = first; e < last; e++) {
+		const bool has_next = e + 1 < last;
+		const SrcMeta m = bcast_meta<SRC_PCM>(lm, e - first, F);
+		const SrcMeta mn = bcast_meta<SRC_PCM>(lm, has_next ? e + 1 - first : e - first, F);
+		const uint32_t flag = (uint32_t)__builtin_amdgcn_readlane((int)my_flag, (int)(e - first));
+
+		// x_full[lane + 64 q]: q < HQ from the history, the rest from this callback's frames
+		float xq[NQ];
+#pragma unroll
+		for (int q = 0; q < HQ; q++) {
+			xq[q] = rawh[q];
+		}
+#pragma unroll
+		for (int q = 0; q < FQ; q++) {
+			const int f = lane + 64 * q;
+			const float mono = (raw[q].left + raw[q].right) * 0.5f;
+			const float t = (float)f * (1.0f / (float)F); // exact for F = 128 .. 512
+			xq[HQ + q] = mono * (m.g1 * t + (1 - t) * m.g0);
+		}
+#ifdef GAS_STAMPS
+		if (e == first) {
+			GAS_UNI_STAMP(2);
+		}
+#endif
+		store_history<HQ>(st.hrtf_hist + (size_t)m.slot * HL, lane, &xq[FQ]); // new history = x_full[F .. F + HL)
+		if constexpr (SRC_PCM) {
+			if (lane == 0 && m.hf) { // advance the playback cursor (audio_spatializer.cpp:378,398)
+				cursors[m.slot].pos = m.pos + m.mixed;
+				if (m.mixed != F) {
+					cursors[m.slot].has_frames = 0;
+				}
+			}
+		}
+		if (has_next) { // the landing registers are free again: the next source's history and frames
+			load_history<HQ>(st.hrtf_hist + (size_t)mn.slot * HL, lane, rawh);
+			load_window<SRC_PCM, FQ>(g, mn, lane, fade_env, raw);
+		}
+		// z = a + i b : a = x_full[0..512), b = x_full[S..S+512) -- one complex FFT serves both sub-blocks
+		float2 zs[8];
+#pragma unroll
+		for (int j = 0; j < 8; j++) {
+			zs[j] = make_float2(xq[j], xq[j + SQ]);
+		}
+		if constexpr (LEAN) {
+			issue_spectra(tab.spec, m.dir, lane, hs); // lands under the transform
+			fwd(zs, lds);
+			products_now(zs, flag, m.row);
+		} else {
+			fwd(zs, lds);
+			products(true, m.dir);
+#pragma unroll
+			for (int j = 0; j < 8; j++) {
+				zp[j] = zs[j];
+			}
+			have_prev = true;
+			prev_flag = flag;
+			prev_row = m.row;
+		}
+	}
+	GAS_UNI_STAMP(3);
+
+	// ---- behind the loop: what nobody waits for ------------------------------------------------------------------
+	if (have) {
+		st.hrtf_prev_gain[lm.slot] = lm.g1;
+		if (!my_flag) { // "not measured": never passes the gate (audio_spatializer.cpp:464-469)
+			*reinterpret_cast<float2 *>(g.peaks + (size_t)lm.row * 2) = make_float2(__builtin_inff(), __builtin_inff());
+		}
+		if (fresh) { // device-published parameter rows go through to the slot table (saves the scatter launch)
+			const float4 *src4 = reinterpret_cast<const float4 *>(fresh + lm.row);
+			float4 *dst4 = reinterpret_cast<float4 *>(st.params + lm.slot);
+#pragma unroll
+			for (int k = 0; k < 8; k++) {
+				dst4[k] = src4[k];
+			}
+		}
+	}
+	// GAS_FLAG_PIPELINED_MIX: waves 2..5 of the first workgroups each sum one float4 column of the PREVIOUS callback's
+	// partial mixes (k_mix_reduce's job, same code, same bits); the rows are requested here and land under the
+	// barrier wait and the last products.  Column -> (workgroup, wave) as in k_hrtf_ols: the 8 columns of one
+	// 128-byte line go to two workgroups of the same XCD.
+	float4 jr[JOB_ROWS];
+	bool job_mine = false;
+	uint32_t job_col = 0;
+	if constexpr (!SRC_PCM) {
+		const uint32_t jw = (uint32_t)(wave - 2), jx = blockIdx.x & 7, ji = blockIdx.x >> 3;
+		job_col = (((ji >> 1) * 8 + jx) * 8) + (ji & 1) * 4 + jw;
+		job_mine = job.partials != nullptr && wave >= 2 && jw < GAS_HRTF_JOB_WAVES && job_col < job.elems / 4; // wave-uniform
+		if (job_mine) {
+			job_issue(job, job_col, lane, jr);
+		}
+	}
+	if constexpr (!LEAN) {
+		products(false, 0); // the last source's products (and peak)
+	}
+
+	// ---- epilogue: spectra of all waves -> fd[wave][ear][j][lane]; wave 0 transforms the left ear's sum and wave 1
+	// the right ear's; the workgroup stores one interleaved time-domain partial mix ----------------------------------
+	float2 *fd = lds_all;
+	float *outp = reinterpret_cast<float *>(lds_all + FD_F2 + 2 * LDS_F2_HALF);
+	if constexpr (!LEAN) {
+		__syncthreads(); // every wave is done with its exchange slices (fd aliases them)
+#pragma unroll
+		for (int j = 0; j < 8; j++) {
+			fd[(wave * 2 + 0) * 512 + j * 64 + lane] = aYL[j];
+			fd[(wave * 2 + 1) * 512 + j * 64 + lane] = aYR[j];
+		}
+	}
+	__syncthreads(); // fd is complete (LEAN: it has been every wave's running sum all along)
+	GAS_UNI_STAMP(4);
+	if (job_mine) {
+		job_finish(job, job_col, lane, jr);
+	}
+	if (wave < 2) {
+		// wave `ear` adds the WAVES spectra of its ear in wave order: ((w0 + w1) + w2) + ...
+		float2 y[8];
+#pragma unroll
+		for (int j = 0; j < 8; j++) {
+			y[j] = fd[wave * 512 + j * 64 + lane];
+		}
+#pragma unroll
+		for (int w = 1; w < UW; w++) {
+#pragma unroll
+			for (int j = 0; j < 8; j++) {
+				y[j] = cadd(y[j], fd[(w * 2 + wave) * 512 + j * 64 + lane]);
+			}
+		}
+		inv(y, lds_all + FD_F2 + wave * LDS_F2_HALF);
+#pragma unroll
+		for (int t = 0; t < SQ; t++) {
+			const int fa = lane + 64 * t, fb = lane + 64 * (SQ + t);
+			outp[fa * 2 + wave] = y[HQ + t].x;
+			outp[fb * 2 + wave] = y[HQ + t].y;
+		}
+	}
+	__syncthreads();
+	for (int idx = threadIdx.x; idx < (int)(F * 2); idx += UW * 64) {
+		my_partial[idx] = outp[idx];
+	}
+	GAS_UNI_STAMP(5);
+}
+
+} // namespace
+
+// One workgroup per CU (one residency round), at least one source per wave, at most 64 (one metadata lane each).
+uint32_t gas_hrtf_uni_partials(uint32_t n) {
+	const uint32_t want = (n + UW - 1) / UW, need = (n + UW * 64 - 1) / (UW * 64);
+	const uint32_t round = UW < 8 ? 256u * (8 / UW) : 256u; // workgroups resident at once
+	const uint32_t w = want < round ? want : round;
+	return w > need ? w : need;
+}
+
+hipError_t gas_launch_hrtf_uni(hipStream_t stream, const gas_group_args &g, const uint32_t *peak_bits, bool peak_all, const gas_dev_state &st, const gas_hrtf_table &tab, const float2 *twiddles, uint32_t frames, uint32_t hist_len, float *partials, uint32_t p_offset, gas_cursor *cursors, const float *fade_env, const gas_params *fresh, const gas_deferred_reduce &job) {
+	if (g.n == 0) {
+		return hipSuccess;
+	}
+	if (frames % 128 != 0 || frames > 512 || hist_len != 512 - frames / 2 || g.order != nullptr) {
+		return hipErrorInvalidValue;
+	}
+	const uint32_t wgs = gas_hrtf_uni_partials(g.n);
+	dim3 grid(wgs), block(UW * 64);
+	const uint32_t all = peak_all ? 1u : 0u;
+#define GAS_UNI_CASE(SQv)                                                                                                                                                     \
+	case SQv:                                                                                                                                                                  \
+		if (cursors) {                                                                                                                                                         \
+			hipLaunchKernelGGL((k_hrtf_uni<SQv, true>), grid, block, 0, stream, g, peak_bits, all, st, tab, twiddles, partials, p_offset, cursors, fade_env, fresh, job);     \
+		} else {                                                                                                                                                               \
+			hipLaunchKernelGGL((k_hrtf_uni<SQv, false>), grid, block, 0, stream, g, peak_bits, all, st, tab, twiddles, partials, p_offset, cursors, fade_env, fresh, job);    \
+		}                                                                                                                                                                      \
+		break;
+	switch (frames / 128) {
+		GAS_UNI_CASE(1)
+		GAS_UNI_CASE(2)
+		GAS_UNI_CASE(3)
+		GAS_UNI_CASE(4)
+		default:
+			return hipErrorInvalidValue;
+	}
+#undef GAS_UNI_CASE
+	return hipGetLastError();
+}
+
+#ifdef GAS_STAMPS
+// Diagnostic builds only: copies the last launch's per-wave stamps ([wave][8] of 100 MHz ticks) to the host.
+extern "C" int gas_debug_read_stamps(unsigned long long *out, unsigned long long count) {
+	const size_t total = sizeof(gas_stamps) / sizeof(gas_stamps[0]);
+	const size_t n = count < total ? count : total;
+	if (hipDeviceSynchronize() != hipSuccess) {
+		return -7;
+	}
+	return hipMemcpyFromSymbol(out, HIP_SYMBOL(gas_stamps), n * sizeof(unsigned long long)) == hipSuccess ? 0 : -7;
+}
+#endif

@@ -84,6 +84,45 @@ __global__ void k_zero_slot(gas_dev_state st, uint32_t slot, uint32_t hist_len, 
 __global__ void k_noop() {
 }
 
+// Same-run copy-bandwidth ceiling: a pure streaming launch over a given byte count -- 16-byte loads
+// summed into a register, 16-byte stores of a constant -- timed exactly like the dominant kernel.  No arithmetic to
+// speak of and every load independent: what this launch achieves is what the memory system gives a launch of this size.
+template <int UNROLL>
+__global__ __launch_bounds__(256) void k_stream_probe(const float4 *__restrict__ rd, uint64_t rd_n4, float4 *__restrict__ wr, uint64_t wr_n4, float *__restrict__ sink) {
+	const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+	float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+	uint64_t i = tid;
+	for (; i + (UNROLL - 1) * stride < rd_n4; i += UNROLL * stride) {
+		float4 v[UNROLL];
+#pragma unroll
+		for (int u = 0; u < UNROLL; u++) {
+			v[u] = rd[i + u * stride];
+		}
+#pragma unroll
+		for (int u = 0; u < UNROLL; u++) {
+			acc.x += v[u].x;
+			acc.y += v[u].y;
+			acc.z += v[u].z;
+			acc.w += v[u].w;
+		}
+	}
+	for (; i < rd_n4; i += stride) {
+		const float4 v = rd[i];
+		acc.x += v.x;
+		acc.y += v.y;
+		acc.z += v.z;
+		acc.w += v.w;
+	}
+	const float4 k = make_float4(1.0f, 2.0f, 3.0f, (float)blockIdx.x);
+	for (uint64_t j = tid; j < wr_n4; j += stride) {
+		wr[j] = k;
+	}
+	if (acc.x + acc.y + acc.z + acc.w == 12345.678f) { // never true for the zero-filled arena; keeps the loads alive
+		sink[tid & 255] = acc.x;
+	}
+}
+
 // Direction order of a launch group's HRTF sources: order[k] = group entry, such that entries with
 // the same HRIR direction are adjacent.  k_hrtf_ols adds the windows of a run of equal-direction sources in the time
 // domain and pays one FFT and one table row for the run.  The order is an optimisation only (any permutation is
@@ -201,6 +240,26 @@ __global__ __launch_bounds__(DIR_WAVES * 64) void k_dir_order(gas_group_args g, 
 }
 
 } // namespace
+
+hipError_t gas_launch_stream_probe(hipStream_t stream, const void *rd, uint64_t rd_bytes, void *wr, uint64_t wr_bytes, uint32_t workgroups, uint32_t unroll, float *sink) {
+	const float4 *r = static_cast<const float4 *>(rd);
+	float4 *w = static_cast<float4 *>(wr);
+	switch (unroll) {
+		case 1:
+			hipLaunchKernelGGL(k_stream_probe<1>, dim3(workgroups), dim3(256), 0, stream, r, rd_bytes / 16, w, wr_bytes / 16, sink);
+			break;
+		case 2:
+			hipLaunchKernelGGL(k_stream_probe<2>, dim3(workgroups), dim3(256), 0, stream, r, rd_bytes / 16, w, wr_bytes / 16, sink);
+			break;
+		case 8:
+			hipLaunchKernelGGL(k_stream_probe<8>, dim3(workgroups), dim3(256), 0, stream, r, rd_bytes / 16, w, wr_bytes / 16, sink);
+			break;
+		default:
+			hipLaunchKernelGGL(k_stream_probe<4>, dim3(workgroups), dim3(256), 0, stream, r, rd_bytes / 16, w, wr_bytes / 16, sink);
+			break;
+	}
+	return hipGetLastError();
+}
 
 hipError_t gas_launch_noop(hipStream_t stream) {
 	hipLaunchKernelGGL(k_noop, dim3(1), dim3(64), 0, stream);

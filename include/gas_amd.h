@@ -296,6 +296,11 @@ int gas_process_block_streams(gas_ctx *ctx, const uint32_t *slots, uint32_t n, u
 /* on = 0 off, 1 = bracket the dominant launch of every callback with HIP events, N > 1 = of every Nth callback. */
 int gas_profile_enable(gas_ctx *ctx, int on);
 int gas_profile_read(gas_ctx *ctx, gas_profile *out, int reset);
+/* Same-run copy-bandwidth ceiling: a pure streaming launch (16-byte loads of read_bytes from an arena
+ * larger than the Infinity Cache, 16-byte stores of write_bytes) timed with the same HIP-event bracket and marker
+ * calibration as the dominant kernel; *out_us = average span of one launch on the GPU timeline over `iters` launches.
+ * workgroups x 256 threads, `unroll` (1, 2, 4 or 8) independent loads in flight per thread. */
+int gas_bandwidth_probe(gas_ctx *ctx, uint64_t read_bytes, uint64_t write_bytes, uint32_t workgroups, uint32_t unroll, uint32_t iters, double *out_us);
 
 #ifdef __cplusplus
 }
