@@ -5,12 +5,29 @@ One "step" = one audio callback: every active source's F-frame AudioFrame buffer
 in HBM) -> per-source spatialization -> N-source stereo mix, through the C ABI (gas_process_block).
 Default workload = BASELINE.json configs[3]'s per-GPU shard (8192 HRTF sources per GPU, 256-tap
 overlap-save, F = 512 @ 48 kHz); at N GPUs the job is 8192*N sources (configs[3] itself at N = 8),
-weak scaling, one process per GPU, partial mixes sum-reduced to rank 0 over RCCL (pipelined one
-callback deep).  `--workload` selects the other configs for ad-hoc runs.
+weak scaling, one process per GPU, partial mixes sum-reduced to rank 0 over RCCL.  `--workload`
+selects the other configs for ad-hoc runs.
 
-Prints ONE JSON line on rank 0 (contract in the task statement): metric/value/unit, roofline of
-the dominant kernel from HIP events recorded inside the library on its launch stream, and the CPU
-baseline (the oracle's reference-equivalent scalar path, 1 core, bounded sample).
+Prints ONE JSON line on rank 0 (contract in the task statement).  How the numbers are taken:
+
+* `value` / `ms_per_step`: EXACTLY --steps callbacks, queued back to back after --warmup untimed ones,
+  bracketed by barrier + torch.cuda.synchronize() on both sides; the time is the span between ONE pair of
+  HIP events recorded on the launch stream around those callbacks (GPU timeline: no host sync latency
+  inside, so 20 steps read the same as 200), MAX over ranks.  The host wall clock around the same
+  region is reported beside it (`wall_ms_per_step`).  No event markers sit inside this pass.
+* This is the library's THROUGHPUT mode (callbacks queued back to back: GAS_FLAG_PIPELINED_MIX sums
+  callback t's partial mixes inside callback t+1's launch; GAS_FLAG_PEAKS_DRAINING_ONLY measures peaks
+  only where the reference reads them).  The contract-faithful figures are in the same line:
+  `ordered` (synchronous two-dispatch callback, what an audio thread runs), `exact_peaks` (ordered,
+  every source's peak), `latency` (one synchronous callback at a time, host-timed p50 / p99).
+* `roofline`: a SEPARATE short pass brackets the dominant launch of every callback with HIP events
+  inside the library (gas_profile_*); `copy_peak` is a pure streaming launch over the same byte count,
+  timed the same way in the same run (gas_bandwidth_probe), i.e. what the memory system gives a
+  launch of this size.
+* `cpu_baseline`: the oracle's reference-equivalent scalar path, 1 core, bounded sample.
+
+HRTF / early-reflection workloads have no reference counterpart: parity for them is against this
+repository's own oracle ("parity unpinned").
 """
 import argparse
 import json
@@ -32,11 +49,13 @@ WORKLOADS = {
 }
 HBM_PEAK = 8.0e12  # MI355X_MICROARCH.md: 8 TB/s spec
 N_SRC_BUFFERS_BYTES = int(os.environ.get("GAS_BENCH_SRC_BYTES", 320 << 20))  # rotate source buffers over > 256 MiB so the Infinity Cache cannot hold them (the override is a cache experiment, never the headline)
+CONDITION_STEPS = 64  # untimed callbacks in front of the --warmup ones: clocks and caches settle independently of --warmup
 
 
 def pmc_traffic(kernel, workload, n_local, peaks, pipelined):
     """HBM bytes per launch from the committed rocprofv3 PMC passes of this same command (profiles/*_pmc.json,
-    written by tools/profile_bench.sh; FETCH_SIZE x2 + WRITE_SIZE), or None."""
+    written by tools/profile_bench.sh; FETCH_SIZE x2 + WRITE_SIZE), or None.  The newest
+    matching record wins (files sort by round)."""
     import glob
 
     best = None
@@ -111,6 +130,164 @@ def cpu_baseline(kind, chain, frames, dirs, hrir, ring, budget_s=10.0):
     return out
 
 
+class Runner:
+    """One context + the bench's callback loop over it: parameters republished every second callback (an emulated
+    60 Hz physics tick), source buffers rotated over more than the Infinity Cache, mixes landing in buckets that are
+    sum-reduced to rank 0 when more than one GPU takes part."""
+
+    def __init__(self, env, flags, n_local, bucket):
+        gas, torch, synth, sharding = env["gas"], env["torch"], env["synth"], env["sharding"]
+        args, kind, chain, frames, ring = env["args"], env["kind"], env["chain"], env["frames"], env["ring"]
+        self.env, self.gas, self.torch = env, gas, torch
+        self.n_local, self.frames, self.flags = n_local, frames, flags
+        self.pipelined = bool(flags & gas.capi.FLAG_PIPELINED_MIX)
+        self.ctx = gas.SpatializerContext(max_sources=n_local, frames=frames, channel_count=1, er_ring_frames=ring, device=env["local_rank"], flags=flags)
+        self.ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+        if env["hrir"] is not None:
+            self.ctx.hrtf_load(env["hrir"])
+        self.slots = self.ctx.source_alloc_many(n_local, kind, chain)
+        self.n_draining = 0
+        if kind == 2 and args.draining_every > 0:
+            for s_ in self.slots[:: args.draining_every]:
+                self.ctx.source_set_draining(int(s_), True)
+                self.n_draining += 1
+        # two physics ticks of parameters, device-resident, alternated every 2 callbacks (SURVEY.md 8d)
+        prng = np.random.default_rng(1234 + 7919 * env["rank"])
+        self.psets = []
+        for _ in range(2):
+            p = synth.draw_params(prng, n_local, dirs=args.dirs, ring_frames=max(ring, 2 * frames), frames=frames)
+            if args.presorted_directions:
+                p["hrtf_dir"] = np.sort(p["hrtf_dir"])
+            if args.xcd_directions:
+                per_wg = max(1, n_local // 256)
+                p["hrtf_dir"] = (prng.integers(0, args.dirs // 8, n_local) * 8 + (np.arange(n_local) // per_wg) % 8).astype(np.uint32)
+            self.psets.append(torch.from_numpy(p.view(np.uint8).reshape(n_local, 128).copy()).cuda())
+        self.ctx.params_publish_batch(self.slots, synth.draw_params(prng, n_local, dirs=args.dirs, ring_frames=max(ring, 2 * frames), frames=frames))
+        # rotating source buffers: synthetic uniform(-0.5, 0.5) AudioFrames, footprint > Infinity Cache; shared by the
+        # runners of one process (the same frames feed every mode)
+        key = (n_local, frames)
+        if key not in env["srcs"]:
+            buf_bytes = n_local * frames * 8
+            n_bufs = max(2, min(16, -(-N_SRC_BUFFERS_BYTES // buf_bytes)))
+            gen = torch.Generator(device="cuda")
+            gen.manual_seed(1234 + env["rank"])
+            env["srcs"][key] = [torch.rand(n_local, frames, 2, device="cuda", generator=gen) - 0.5 for _ in range(n_bufs)]
+        self.srcs = env["srcs"][key]
+        self.n_bufs = len(self.srcs)
+        # Partial mixes land in buckets of B callbacks; on N > 1 GPUs each full bucket is sum-reduced to rank 0 in ONE
+        # collective (B x 4 KiB) on a side stream while the next bucket is being computed: the 4 KiB per-callback
+        # message is latency-bound over xGMI.  That is a THROUGHPUT arrangement (callbacks queued back to back, the
+        # mix of a callback reaches rank 0 up to B callbacks later); a real-time host uses --reduce-bucket 1.
+        self.B = B = max(1, bucket)
+        self.buckets = [torch.zeros(B, 1, frames, 2, device="cuda") for _ in range(2)]
+        self.peaks = torch.zeros(n_local, 2, device="cuda")
+        self.comm_stream = torch.cuda.Stream() if env["world"] > 1 else None
+        self.reducer = sharding.PartialMixReducer(env["dist"] if env["world"] > 1 else None, root=0, comm_stream=self.comm_stream)
+        self.pending = [None, None]
+        rc = self.ctx.process_block_raw(self.srcs[0].data_ptr(), self.slots, n_local, frames, self.buckets[0][0].data_ptr(), self.peaks.data_ptr(), gas.capi.MEM_DEVICE)
+        if rc != 0:
+            raise SystemExit(f"gas_process_block failed: {rc}")
+        torch.cuda.synchronize()
+        # raw device addresses, looked up once: tensor indexing costs microseconds per call and this loop is the host
+        # side of a ~20 us callback
+        self.pset_ptr = [t.data_ptr() for t in self.psets]
+        self.src_ptr = [t.data_ptr() for t in self.srcs]
+        self.out_ptr = [[self.buckets[b][i].data_ptr() for i in range(B)] for b in range(2)]
+        self.peaks_ptr = self.peaks.data_ptr()
+
+    def step(self, k):
+        ctx, B, n, F = self.ctx, self.B, self.n_local, self.frames
+        if k % 2 == 0:
+            ctx.params_publish_device(self.pset_ptr[(k // 2) % 2], n)
+        b, i = (k // B) % 2, k % B
+        if i == 0:
+            self.reducer.wait(self.pending[b])  # the bucket's previous reduce must be done before it is rewritten
+            self.pending[b] = None
+        rc = ctx.process_block_raw(self.src_ptr[k % self.n_bufs], None, n, F, self.out_ptr[b][i], self.peaks_ptr, 1)
+        if rc != 0:
+            raise SystemExit(f"gas_process_block failed: {rc}")
+        if self.pipelined:
+            # the last mix of the previous bucket rode in the launch above: that bucket is complete in stream order now
+            if i == 0 and k > 0:
+                self.pending[1 - b] = self.reducer.reduce(self.buckets[1 - b])
+        elif i == B - 1:
+            self.pending[b] = self.reducer.reduce(self.buckets[b])
+
+    def drain(self, k_end):
+        # the bucket holding the last callback still has to reach rank 0: always in pipelined mode (its reduce is
+        # issued one callback late), else only when it is partly filled
+        B = self.B
+        if k_end > 0 and (self.pipelined or k_end % B != 0):
+            b = ((k_end - 1) // B) % 2
+            self.reducer.wait(self.pending[b])
+            self.ctx.join_outputs()  # enqueue the pending sum of the last callback
+            self.pending[b] = self.reducer.reduce(self.buckets[b])
+        for i in range(2):
+            self.reducer.wait(self.pending[i])
+            self.pending[i] = None
+        if self.comm_stream is not None:
+            self.torch.cuda.current_stream().wait_stream(self.comm_stream)
+
+    def fence(self):
+        torch, env = self.torch, self.env
+        torch.cuda.synchronize()
+        if env["world"] > 1:
+            env["dist"].barrier()
+            torch.cuda.synchronize()
+
+    def timed(self, steps, warmup):
+        """(GPU-timeline ms, wall ms, host enqueue ms) of exactly `steps` callbacks, every output complete inside."""
+        torch = self.torch
+        n_pre = max(0, CONDITION_STEPS - warmup) + warmup
+        for k in range(n_pre):
+            self.step(k)
+        self.drain(n_pre)
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        self.fence()
+        t0 = time.perf_counter()
+        ev0.record()
+        for k in range(steps):
+            self.step(k)
+        t_enq = time.perf_counter() - t0
+        self.drain(steps)
+        ev1.record()
+        self.fence()
+        dt_wall = time.perf_counter() - t0
+        return ev0.elapsed_time(ev1), dt_wall * 1e3, t_enq * 1e3
+
+    def marked(self, callbacks):
+        """Dominant-kernel time from HIP events recorded inside the library around every callback's main launch."""
+        self.ctx.profile_enable(1)
+        self.ctx.profile_read(reset=True)
+        for k in range(callbacks):
+            self.step(k)
+        self.drain(callbacks)
+        self.torch.cuda.synchronize()
+        prof = self.ctx.profile_read(reset=True)
+        self.ctx.profile_enable(False)
+        return prof
+
+    def latency(self, callbacks):
+        """Synchronous callbacks one at a time (publish every second one, process_block, wait for the mix): host-timed."""
+        ctx, n, F = self.ctx, self.n_local, self.frames
+        out = self.out_ptr[0][0]
+        ts = []
+        for k in range(callbacks + 16):
+            t0 = time.perf_counter()
+            if k % 2 == 0:
+                ctx.params_publish_device(self.pset_ptr[(k // 2) % 2], n)
+            rc = ctx.process_block_raw(self.src_ptr[k % self.n_bufs], None, n, F, out, self.peaks_ptr, 1)
+            ctx.synchronize()
+            ts.append(time.perf_counter() - t0)
+            if rc != 0:
+                raise SystemExit(f"gas_process_block failed: {rc}")
+        a = np.sort(np.array(ts[16:])) * 1e3
+        return {"callbacks": callbacks, "p50_ms": float(a[len(a) // 2]), "p99_ms": float(a[min(len(a) - 1, int(np.ceil(0.99 * len(a))) - 1)]), "max_ms": float(a[-1])}
+
+    def close(self):
+        self.ctx.close()
+
+
 def main():
     if len(sys.argv) >= 4 and sys.argv[1] == "--cpu-worker":  # child of cpu_baseline(): CPU only, prints seconds
         kind, chain, frames, dirs, hp, ring, n, blocks = json.loads(sys.argv[2])
@@ -126,15 +303,16 @@ def main():
     ap.add_argument("--dirs", type=int, default=1024)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-max-sources", action="store_true")
-    ap.add_argument("--profile-every", type=int, default=-1, help="bracket the dominant kernel of every Nth step with HIP events; a marked step costs ~5 us more, so the default (-1) marks about 12-16 steps of the run: N = clamp(steps // 12, 1, 16); 0 = no markers")
-    ap.add_argument("--reduce-bucket", type=int, default=32, help="callbacks per cross-GPU reduce (N > 1)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the ordered / exact-peaks / latency / copy-ceiling / max-sources passes (profiling runs)")
+    ap.add_argument("--marked-callbacks", type=int, default=48, help="callbacks of the separate pass that brackets the dominant launch with HIP events (0 = none: roofline fields empty)")
+    ap.add_argument("--reduce-bucket", type=int, default=32, help="callbacks per cross-GPU reduce (N > 1); 1 = every callback's mix is reduced on its own (real-time arrangement)")
     ap.add_argument("--crossfade", action="store_true", help="GAS_FLAG_HRTF_CROSSFADE: blend old/new HRIRs when a source's direction changes (SURVEY 8f#4)")
-    ap.add_argument("--no-pipelined-mix", action="store_true", help="without GAS_FLAG_PIPELINED_MIX: the partial-mix sum of callback t runs before callback t+1's DSP kernel instead of under it")
+    ap.add_argument("--no-pipelined-mix", action="store_true", help="headline without GAS_FLAG_PIPELINED_MIX: the partial-mix sum of callback t runs before callback t+1's DSP kernel instead of under it")
     ap.add_argument("--direction-order", action="store_true", help="GAS_FLAG_DIRECTION_ORDER: let the library group sources by HRIR direction (device sort per publish)")
     ap.add_argument("--presorted-directions", action="store_true", help="GAS_FLAG_DIRECTION_RUNS with parameters whose HRIR directions are grouped in callback order (what a caller that sorts its list gets)")
     ap.add_argument("--xcd-directions", action="store_true", help="experiment: draw each source's HRIR direction from the eighth of the table that belongs to its workgroup's XCD (upper bound of an XCD-aware source partition)")
     ap.add_argument("--draining-every", type=int, default=64, help="1 source in N has ended its stream (exact peak needed, audio_spatializer.cpp:464-469); 0 = none")
-    ap.add_argument("--exact-peaks", action="store_true", help="per-source inverse FFTs for every source (exact peak of every source)")
+    ap.add_argument("--exact-peaks", action="store_true", help="headline with the exact peak of every source")
     args = ap.parse_args()
 
     import torch
@@ -170,138 +348,40 @@ def main():
 
     rng = np.random.default_rng(1234)
     hrir = synth.synthetic_hrir(rng, dirs=args.dirs) if 3 in chain else None
+    env = {"gas": gas, "torch": torch, "synth": synth, "sharding": sharding, "dist": dist, "args": args, "kind": kind, "chain": chain, "frames": frames, "ring": ring, "hrir": hrir, "rank": rank, "local_rank": local_rank, "world": world, "srcs": {}}
+
+    K = gas.capi
     # Peaks are produced where the reference consumes them: playbacks whose stream has ended
-    # (audio_spatializer.cpp:464-469).  1 source in 64 is in that state here; the rest take the
-    # frequency-domain accumulation path.  --exact-peaks measures every source's peak instead.
-    flags = 0 if args.exact_peaks else gas.capi.FLAG_PEAKS_DRAINING_ONLY
+    # (audio_spatializer.cpp:464-469).  1 source in 64 is in that state here.  --exact-peaks measures every source's.
+    base_flags = 0 if args.exact_peaks else K.FLAG_PEAKS_DRAINING_ONLY
     if args.crossfade:
-        flags |= gas.capi.FLAG_HRTF_CROSSFADE
+        base_flags |= K.FLAG_HRTF_CROSSFADE
     if args.direction_order:
-        flags |= gas.capi.FLAG_DIRECTION_ORDER
+        base_flags |= K.FLAG_DIRECTION_ORDER
     if args.presorted_directions:
-        flags |= gas.capi.FLAG_DIRECTION_RUNS
-    if not args.no_pipelined_mix:
-        flags |= gas.capi.FLAG_PIPELINED_MIX  # callbacks are queued back to back here: overlap the tiny reduce with the next DSP kernel
-    ctx = gas.SpatializerContext(max_sources=n_local, frames=frames, channel_count=1, er_ring_frames=ring, device=local_rank, flags=flags)
-    stream = torch.cuda.current_stream()
-    ctx.set_stream(stream.cuda_stream)
-    if hrir is not None:
-        ctx.hrtf_load(hrir)
-    slots = ctx.source_alloc_many(n_local, kind, chain)
-    n_draining = 0
-    if kind == 2:
-        for s_ in (slots[:: args.draining_every] if args.draining_every > 0 else []):
-            ctx.source_set_draining(int(s_), True)
-            n_draining += 1
+        base_flags |= K.FLAG_DIRECTION_RUNS
+    head_flags = base_flags | (0 if args.no_pipelined_mix else K.FLAG_PIPELINED_MIX)
 
-    # two physics ticks of parameters, device-resident, alternated every 2 callbacks
-    prng = np.random.default_rng(1234 + 7919 * rank)
-    psets = []
-    for _ in range(2):
-        p = synth.draw_params(prng, n_local, dirs=args.dirs, ring_frames=max(ring, 2 * frames), frames=frames)
-        if args.presorted_directions:
-            p["hrtf_dir"] = np.sort(p["hrtf_dir"])
-        if args.xcd_directions:
-            per_wg = max(1, n_local // 256)
-            p["hrtf_dir"] = (prng.integers(0, args.dirs // 8, n_local) * 8 + (np.arange(n_local) // per_wg) % 8).astype(np.uint32)
-        psets.append(torch.from_numpy(p.view(np.uint8).reshape(n_local, 128).copy()).cuda())
-    ctx.params_publish_batch(slots, synth.draw_params(prng, n_local, dirs=args.dirs, ring_frames=max(ring, 2 * frames), frames=frames))
-
-    # rotating source buffers: synthetic uniform(-0.5, 0.5) AudioFrames, footprint > Infinity Cache
-    buf_bytes = n_local * frames * 8
-    n_bufs = max(2, min(16, -(-N_SRC_BUFFERS_BYTES // buf_bytes)))
-    gen = torch.Generator(device="cuda")
-    gen.manual_seed(1234 + rank)
-    srcs = [torch.rand(n_local, frames, 2, device="cuda", generator=gen) - 0.5 for _ in range(n_bufs)]
-    # Partial mixes land in buckets of B callbacks; on N > 1 GPUs each full bucket is sum-reduced to rank 0
-    # in ONE collective (B x 4 KiB) on a side stream while the next bucket is being computed: the 4 KiB
-    # per-callback message is latency-bound over xGMI, so it is batched instead of sent 40 000 times a second.
-    # Added latency = B callbacks of compute (32 * ~20 us = 0.65 ms), far inside the 10.67 ms real-time budget.
-    B = max(1, args.reduce_bucket)
-    buckets = [torch.zeros(B, 1, frames, 2, device="cuda") for _ in range(2)]
-    peaks = torch.zeros(n_local, 2, device="cuda")
-
-    comm_stream = torch.cuda.Stream() if world > 1 else None
-    reducer = sharding.PartialMixReducer(dist if world > 1 else None, root=0, comm_stream=comm_stream)
-    pending = [None, None]
-
-    rc = ctx.process_block_raw(srcs[0].data_ptr(), slots, n_local, frames, buckets[0][0].data_ptr(), peaks.data_ptr(), gas.capi.MEM_DEVICE)
-    if rc != 0:
-        raise SystemExit(f"gas_process_block failed: {rc}")
-    torch.cuda.synchronize()
-
-    # raw device addresses, looked up once: tensor indexing costs microseconds per call and this loop is the host side
-    # of a ~20 us callback
-    pset_ptr = [t.data_ptr() for t in psets]
-    src_ptr = [t.data_ptr() for t in srcs]
-    out_ptr = [[buckets[b][i].data_ptr() for i in range(B)] for b in range(2)]
-    peaks_ptr = peaks.data_ptr()
-
-    pipelined = not args.no_pipelined_mix
-
-    def step(k):
-        if k % 2 == 0:
-            ctx.params_publish_device(pset_ptr[(k // 2) % 2], n_local)
-        b, i = (k // B) % 2, k % B
-        if i == 0:
-            reducer.wait(pending[b])  # the bucket's previous reduce must be done before it is rewritten
-            pending[b] = None
-        rc = ctx.process_block_raw(src_ptr[k % n_bufs], None, n_local, frames, out_ptr[b][i], peaks_ptr, gas.capi.MEM_DEVICE)
-        if rc != 0:
-            raise SystemExit(f"gas_process_block failed: {rc}")
-        if pipelined:
-            # the last mix of the previous bucket rode in the launch above: that bucket is complete in stream order now
-            if i == 0 and k > 0:
-                pending[1 - b] = reducer.reduce(buckets[1 - b])
-        elif i == B - 1:
-            pending[b] = reducer.reduce(buckets[b])
-
-    def drain(k_end):
-        # the bucket holding the last callback still has to reach rank 0: always in pipelined mode (its reduce is
-        # issued one callback late), else only when it is partly filled
-        if k_end > 0 and (pipelined or k_end % B != 0):
-            b = ((k_end - 1) // B) % 2
-            reducer.wait(pending[b])
-            ctx.join_outputs()  # enqueue the pending sum of the last callback
-            pending[b] = reducer.reduce(buckets[b])
-        for i in range(2):
-            reducer.wait(pending[i])
-            pending[i] = None
-
-    for k in range(args.warmup):
-        step(k)
-    drain(args.warmup)
-    profile_every = args.profile_every if args.profile_every >= 0 else max(1, min(16, args.steps // 12))
-    ctx.profile_enable(profile_every)
-    ctx.profile_read(reset=True)
-    torch.cuda.synchronize()
+    # ---- headline pass: exactly --steps callbacks, no markers inside -----------------------------------------------
+    run = Runner(env, head_flags, n_local, args.reduce_bucket)
+    gpu_ms, wall_ms, enq_ms = run.timed(args.steps, args.warmup)
     if world > 1:
-        dist.barrier()
-        torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        step(k)
-    t_enq = time.perf_counter() - t0
-    drain(args.steps)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-        torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    prof = ctx.profile_read(reset=True)
-    ctx.profile_enable(False)
-    if world > 1:
-        tmax = torch.tensor([dt], device="cuda" if backend == "nccl" else "cpu", dtype=torch.float64)
+        tmax = torch.tensor([gpu_ms, wall_ms], device="cuda" if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
-
-    ms_per_step = dt / args.steps * 1e3
-    value = n_total * frames * args.steps / dt
+        gpu_ms, wall_ms = float(tmax[0].item()), float(tmax[1].item())
+    ms_per_step = gpu_ms / args.steps
+    value = n_total * frames * args.steps / (gpu_ms * 1e-3)
+    # ---- marked pass: the dominant kernel's span, events inside the library ----------------------------------------
+    prof = run.marked(args.marked_callbacks) if args.marked_callbacks > 0 else {"launches": 0, "kernel_ms": 0.0, "bytes_per_launch": 0, "kernel": ""}
+    n_draining = run.n_draining
 
     result = None
+    achieved = 0.0
+    peaks_desc = "every source" if args.exact_peaks else f"draining sources only ({n_draining} of {n_local} per GPU)"
     if rank == 0:
         k_ms = prof["kernel_ms"] / max(prof["launches"], 1)
         achieved = prof["bytes_per_launch"] / (k_ms * 1e-3) if k_ms > 0 else 0.0
+        rccl_ranks = dist.get_world_size() if world > 1 else 1
         result = {
             "metric": "mixed AudioFrames/s",
             "value": value,
@@ -315,8 +395,12 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
+            "wall_ms_per_step": wall_ms / args.steps,
             "config": {
                 "workload": desc,
+                "mode": ("ordered (synchronous two-dispatch callback)" if args.no_pipelined_mix else "throughput: callbacks queued back to back, GAS_FLAG_PIPELINED_MIX (the sum of callback t's partial mixes rides in callback t+1's launch)") + ("" if args.exact_peaks else " + GAS_FLAG_PEAKS_DRAINING_ONLY"),
+                "timing": f"one HIP event pair on the launch stream around the {args.steps} callbacks (GPU timeline), {CONDITION_STEPS} untimed conditioning callbacks in front, max over ranks; wall_ms_per_step = host clock around the same region incl. the closing synchronize",
+                "parity": "unpinned: HRTF / early reflections have no reference counterpart, outputs are checked against this repository's oracle (DESIGN.md section 0)" if (3 in chain or 2 in chain) else "oracle restates audio_spatializer_3d.cpp:554-609; engine primitives unpinned (DESIGN.md section 0)",
                 "sources_total": n_total,
                 "sources_per_gpu": n_local,
                 "frames_per_callback": frames,
@@ -324,9 +408,10 @@ def main():
                 "hrir_directions": args.dirs if hrir is not None else 0,
                 "hrir_crossfade": bool(args.crossfade),
                 "pipelined_mix": not args.no_pipelined_mix,
-                "host_enqueue_us_per_step": t_enq / args.steps * 1e6,
-                "peaks": "every source" if args.exact_peaks else f"draining sources only ({n_draining} of {n_local} per GPU)",
-                "parallelism": f"source-sharded x{world}, RCCL sum-reduce to rank 0 of {B} callbacks' partial mixes ({B * frames * 8} B) per collective, pipelined on a side stream" if world > 1 else "single GPU",
+                "host_enqueue_us_per_step": enq_ms / args.steps * 1e3,
+                "peaks": peaks_desc,
+                "parallelism": (f"source-sharded x{world} (world {world}, this rank on cuda:{local_rank}, {backend} reports {rccl_ranks} ranks), sum-reduce to rank 0 of {run.B} callbacks' partial mixes ({run.B * frames * 8} B) per collective on a side stream" + (" -- throughput arrangement: a callback's mix reaches rank 0 up to that many callbacks later; --reduce-bucket 1 is the real-time arrangement" if run.B > 1 else "")) if world > 1 else "single GPU (world 1, cuda:%d)" % local_rank,
+                "reduce_bucket": run.B,
                 "realtime_budget_ms": frames / 48000.0 * 1e3,
             },
             "roofline": {
@@ -343,19 +428,61 @@ def main():
                 "algorithmic_bytes_per_launch": prof["bytes_per_launch"],
             },
         }
-
-    if rank == 0:
-        t = pmc_traffic(result["roofline"]["kernel"], desc, n_local, result["config"].get("peaks"), bool(result["config"].get("pipelined_mix")))
+        t = pmc_traffic(result["roofline"]["kernel"], desc, n_local, peaks_desc, not args.no_pipelined_mix)
         if t:
-            result["roofline"]["traffic"] = t[0] / 1e9 * 1e9  # bytes per launch
+            result["roofline"]["traffic"] = float(t[0])  # bytes per launch
             result["roofline"]["traffic_source"] = "profiles/" + t[1] + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command; FETCH x2 on gfx950)"
 
-    # ---- extras on one GPU: max concurrent sources inside the 10.67 ms callback, CPU baseline ----
-    del srcs
-    ctx.close()
+    # ---- extras on one GPU ------------------------------------------------------------------------------------------
+    extras = rank == 0 and world == 1 and not args.no_extras
+    if extras:
+        try:
+            # same-run copy-bandwidth ceiling over the dominant launch's algorithmic bytes (reads: frames + history +
+            # taps; writes: history + partial mixes), best of a few launch geometries
+            B_alg = int(result["roofline"]["algorithmic_bytes_per_launch"]) or n_local * frames * 8
+            wr = (n_local * (512 - frames // 2) * 4 if 3 in chain else 0) + (1 << 20)
+            wr = min(wr, B_alg // 2) // 16 * 16
+            rd = (B_alg - wr) // 16 * 16
+            best = None
+            for wgs, unroll in ((2048, 8), (4096, 8), (4096, 4), (1024, 2), (512, 4)):
+                us = run.ctx.bandwidth_probe(rd, wr, wgs, unroll, 24)
+                if best is None or us < best[0]:
+                    best = (us, wgs, unroll)
+            copy_bps = (rd + wr) / (best[0] * 1e-6)
+            result["roofline"].update({"copy_us": best[0], "copy_peak": copy_bps / 1e9, "frac_of_copy": (achieved / copy_bps) if copy_bps > 0 else None, "copy_probe": f"gas_bandwidth_probe: {rd} B read from a rotating 320 MiB arena + {wr} B written, {best[1]} workgroups x 256 threads, {best[2]} loads in flight per thread, same event bracket as kernel_us"})
+        except Exception as e:
+            result["roofline"]["copy_error"] = repr(e)
+    run.close()
+    del run
+    if extras:
+        try:
+            ord_flags = base_flags & ~K.FLAG_PIPELINED_MIX
+            r2 = Runner(env, ord_flags, n_local, 1)
+            g2, w2, _ = r2.timed(200, 20)
+            p2 = r2.marked(32)
+            result["ordered"] = {"ms_per_step": g2 / 200, "value": n_local * frames * 200 / (g2 * 1e-3), "wall_ms_per_step": w2 / 200, "kernel_us": p2["kernel_ms"] / max(p2["launches"], 1) * 1e3, "steps": 200, "what": "no GAS_FLAG_PIPELINED_MIX: DSP kernel + k_mix_reduce per callback, as a synchronous audio callback runs; peaks: " + peaks_desc}
+            lat = {"sources": n_local, **r2.latency(256)}
+            r2.close()
+            del r2
+            if kind == 2 and not args.exact_peaks:
+                r3 = Runner(env, 0, n_local, 1)
+                g3, w3, _ = r3.timed(200, 20)
+                p3 = r3.marked(32)
+                result["exact_peaks"] = {"ms_per_step": g3 / 200, "value": n_local * frames * 200 / (g3 * 1e-3), "kernel_us": p3["kernel_ms"] / max(p3["launches"], 1) * 1e3, "steps": 200, "what": "ordered mode, exact output peak of every source (no GAS_FLAG_PEAKS_DRAINING_ONLY): the reference's per-playback peak computed for all"}
+                r3.close()
+                del r3
+            result["latency"] = {"what": "one synchronous callback at a time (device-resident parameter publish every second callback + gas_process_block + gas_ctx_synchronize), ordered mode, host clock", "budget_ms": frames / 48000.0 * 1e3, "runs": [lat]}
+            if args.workload == "hrtf" and n_local == 8192:
+                r4 = Runner(env, ord_flags, 10240, 1)  # the north star's ">= 10^4 sources inside one callback", stated directly
+                result["latency"]["runs"].append({"sources": 10240, **r4.latency(256)})
+                r4.close()
+                del r4
+        except Exception as e:  # the extras must never cost the headline line
+            result["extras_error"] = repr(e)
+    env["srcs"].clear()
     torch.cuda.empty_cache()
     if rank == 0 and world == 1:
-        if not args.no_max_sources and args.workload.startswith("hrtf"):
+        if not args.no_max_sources and args.workload.startswith("hrtf") and not args.no_extras:
             try:
                 result["max_sources_under_10ms"] = probe_max_sources(gas, synth, torch, kind, chain, frames, hrir, args.dirs)
             except Exception as e:  # the probe must never cost the headline line
@@ -369,9 +496,10 @@ def main():
         dist.destroy_process_group()
 
 
-def probe_max_sources(gas, synth, torch, kind, chain, frames, hrir, dirs):
-    """Largest N (from a fixed ladder) whose p99 callback time stays under 10 ms on one GPU.  One context sized
-    for the top rung; each rung runs the first N slots."""
+def probe_max_sources(gas, synth, torch, kind, chain, frames, hrir, dirs, samples=100):
+    """Largest N (from a fixed ladder) whose p99 callback time stays under 10 ms on one GPU: `samples` synchronous
+    callbacks per rung, host clock around gas_process_block + synchronize.  One context sized for the top rung; each
+    rung runs the first N slots."""
     ladder = [1 << 20, 1 << 21, 3 << 20, 1 << 22, 5 << 20, 6 << 20, 7 << 20]
     top = ladder[-1]
     best = None
@@ -393,14 +521,15 @@ def probe_max_sources(gas, synth, torch, kind, chain, frames, hrir, dirs):
                 break
             torch.cuda.synchronize()
             times = []
-            for _ in range(16):
+            for _ in range(samples + 2):
                 t0 = time.perf_counter()
                 ctx.process_block_raw(src.data_ptr(), None, n, frames, out.data_ptr(), peaks.data_ptr(), 1)
                 torch.cuda.synchronize()
                 times.append(time.perf_counter() - t0)
-            p99 = float(np.sort(times[2:])[-1]) * 1e3
+            a = np.sort(np.array(times[2:])) * 1e3
+            p99 = float(a[min(len(a) - 1, int(np.ceil(0.99 * len(a))) - 1)])
             if p99 < 10.0:
-                best = {"sources": n, "p99_callback_ms": p99}
+                best = {"sources": n, "p50_callback_ms": float(a[len(a) // 2]), "p99_callback_ms": p99, "max_callback_ms": float(a[-1]), "samples": samples}
             else:
                 break
         del src, out, peaks

@@ -172,6 +172,7 @@ struct gas_ctx {
 	double prof_ms = 0.0;
 	uint64_t prof_bytes = 0;
 	int prof_group = -1;
+	bool prof_uni = false; // the timed launch was k_hrtf_uni
 	double ev_overhead_ms = 0.0; // marker/dispatch overhead of an event pair around one launch (calibrated)
 	uint32_t prof_every = 1, prof_tick = 0; // bracket every Nth callback's dominant launch
 
@@ -568,6 +569,7 @@ int run_groups(gas_ctx *c, const gas_audio_frame *d_src, const uint32_t *d_slots
 				c->prof_bytes += group_bytes(c, gt + 1, groups[gt + 1].count) - group_bytes(c, gt + 1, 0);
 			}
 			c->prof_group = gt;
+			c->prof_uni = gt == G_FX_HRTF && uni_hrtf && groups[G_FX_HRTF_PK].count == 0;
 		}
 		p_off += pcount[gt];
 	}
@@ -1852,7 +1854,7 @@ int gas_profile_read(gas_ctx *c, gas_profile *out, int reset) {
 	out->kernel_ms = c->prof_ms;
 	out->bytes_per_launch = c->prof_bytes;
 	if (c->prof_group >= 0) {
-		std::strncpy(out->kernel_name, k_group_kernel[c->prof_group], sizeof(out->kernel_name) - 1);
+		std::strncpy(out->kernel_name, c->prof_uni ? "k_hrtf_uni" : k_group_kernel[c->prof_group], sizeof(out->kernel_name) - 1);
 	}
 	if (reset) {
 		c->prof_launches = 0;

@@ -4,5 +4,5 @@
 ARGS=$1; shift
 for lib in "$@"; do
   if [ "$lib" = "-" ]; then unset GAS_AMD_LIB; else export GAS_AMD_LIB=$PWD/$lib; fi
-  python3 bench.py --steps 300 --warmup 30 --no-cpu-baseline --no-max-sources --profile-every 1 $ARGS 2>/dev/null | tail -1 | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print('%-32s %8.2f us/step  kernel %7.2f us' % (sys.argv[1], 1e3*d['ms_per_step'], d['roofline']['kernel_us']))" "$lib"
+  python3 bench.py --steps 300 --warmup 30 --no-cpu-baseline --no-extras $ARGS 2>/dev/null | tail -1 | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print('%-32s %8.2f us/step  kernel %7.2f us' % (sys.argv[1], 1e3*d['ms_per_step'], d['roofline']['kernel_us']))" "$lib"
 done

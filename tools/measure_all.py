@@ -13,7 +13,7 @@ sys.path.insert(0, ROOT)
 
 
 def bench(args):
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--no-max-sources"] + args, capture_output=True, text=True).stdout
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--no-extras"] + args, capture_output=True, text=True).stdout
     return json.loads([l for l in out.splitlines() if l.startswith("{")][-1])
 
 

@@ -84,7 +84,42 @@ def main(out):
             print(f"{k[:70]:70s} dispatches={n:6d} avg={s / n:14.1f} KiB")
 
 
+def sq_summary(out):
+    """Per-dispatch averages of the SQ pass for the library's kernels (quad-cycle units, MI355X_MICROARCH.md)."""
+    cc = find(os.path.join(out, "sq"), "*counter_collection.csv")
+    print("== rocprofv3 --pmc SQ_* (per-dispatch average) ==")
+    if not cc:
+        print("missing")
+        return
+    agg = defaultdict(lambda: defaultdict(lambda: [0.0, 0]))
+    with open(cc) as f:
+        for r in csv.DictReader(f):
+            a = agg[r["Kernel_Name"][:70]][r["Counter_Name"]]
+            a[0] += float(r["Counter_Value"])
+            a[1] += 1
+    for k, d in agg.items():
+        if "k_" not in k:
+            continue
+        print(k)
+        for c, (s, n) in sorted(d.items()):
+            print(f"   {c:24s} {s / n:16.1f}   ({n} dispatches)")
+
+
+def bench_line(out):
+    """The JSON line bench.py printed under the tracer (its event-timed kernel_us next to the trace's average)."""
+    import json
+
+    for l in open(os.path.join(out, "trace.log")):
+        if l.startswith("{"):
+            d = json.loads(l)
+            rf = d["roofline"]
+            print("== bench.py line of the traced run ==")
+            print(f"ms_per_step {d['ms_per_step']:.5f}  value {d['value']:.4e}  kernel {rf['kernel']} kernel_us(events) {rf['kernel_us']:.2f}  algorithmic bytes {rf['algorithmic_bytes_per_launch']}  frac {rf['frac']:.3f}")
+
+
 if __name__ == "__main__":
     main(sys.argv[1])
+    sq_summary(sys.argv[1])
+    bench_line(sys.argv[1])
     if len(sys.argv) > 2:
         write_pmc_json(sys.argv[1], sys.argv[2])
