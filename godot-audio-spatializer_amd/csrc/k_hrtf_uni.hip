@@ -78,6 +78,11 @@ __global__ __launch_bounds__(UW * 64, LEAN ? 3 : GAS_HRTF_WAVES_PER_SIMD) void k
 	float2 *acc = lds_all + wave * 2 * 512; // LEAN: this wave's fd rows (left ear, then right)
 	float *my_partial = partials + ((size_t)p_offset + blockIdx.x) * (size_t)(F * 2);
 	GAS_UNI_STAMP(0);
+#ifdef GAS_STAMPS
+	if (lane == 0 && (blockIdx.x * UW + wave) < 8192) { // shader-clock stamp next to the 100 MHz one: cycles per tick = clock
+		gas_stamps[(blockIdx.x * UW + wave) * GAS_STAMP_SLOTS + 6] = __builtin_amdgcn_s_memtime();
+	}
+#endif
 
 	// ---- prologue: nothing in front of the first source's frames that they do not depend on -------------------
 	constexpr int TW_PER = (512 + UW * 64 - 1) / (UW * 64); // 16-byte pieces of the 8 KiB twiddle table per thread
@@ -155,6 +160,13 @@ __global__ __launch_bounds__(UW * 64, LEAN ? 3 : GAS_HRTF_WAVES_PER_SIMD) void k
 			fft512<true>(v, t1, t2, slice, lane);
 		}
 	};
+	// gain ramp weights of this lane's frames, t = f/F and 1 - t (exact for F = 128 .. 512): the same for every source
+	float tq[FQ], omtq[FQ];
+#pragma unroll
+	for (int q = 0; q < FQ; q++) {
+		tq[q] = (float)(lane + 64 * q) * (1.0f / (float)F);
+		omtq[q] = 1 - tq[q];
+	}
 	GAS_UNI_STAMP(1);
 
 	// ---- source loop: one forward FFT per source; its spectral products are taken one transform later (the HRIR
@@ -264,8 +276,8 @@ __global__ __launch_bounds__(UW * 64, LEAN ? 3 : GAS_HRTF_WAVES_PER_SIMD) void k
 		for (int q = 0; q < FQ; q++) {
 			const int f = lane + 64 * q;
 			const float mono = (raw[q].left + raw[q].right) * 0.5f;
-			const float t = (float)f * (1.0f / (float)F); // exact for F = 128 .. 512
-			xq[HQ + q] = mono * (m.g1 * t + (1 - t) * m.g0);
+			xq[HQ + q] = mono * (m.g1 * tq[q] + omtq[q] * m.g0);
+			(void)f;
 		}
 #ifdef GAS_STAMPS
 		if (e == first) {
@@ -296,6 +308,8 @@ __global__ __launch_bounds__(UW * 64, LEAN ? 3 : GAS_HRTF_WAVES_PER_SIMD) void k
 			fwd(zs, lds);
 			products_now(zs, flag, m.row);
 		} else {
+			// the products of a transform are taken one transform later (measured: taking them in front of the next
+			// transform instead, which saves the 16-register copy, costs 0.5 us per launch -- the row needs the time)
 			fwd(zs, lds);
 			products(true, m.dir);
 #pragma unroll
@@ -387,6 +401,11 @@ __global__ __launch_bounds__(UW * 64, LEAN ? 3 : GAS_HRTF_WAVES_PER_SIMD) void k
 		my_partial[idx] = outp[idx];
 	}
 	GAS_UNI_STAMP(5);
+#ifdef GAS_STAMPS
+	if (lane == 0 && (blockIdx.x * UW + wave) < 8192) {
+		gas_stamps[(blockIdx.x * UW + wave) * GAS_STAMP_SLOTS + 7] = __builtin_amdgcn_s_memtime();
+	}
+#endif
 }
 
 } // namespace

@@ -68,13 +68,18 @@ def main():
     t0 = st[:, 0].min()
     names = ["entry", "prologue issued", "first data", "loop done", "epilogue barrier 1", "partial stored", "kernargs arrived", "slot/row lists arrived"]
     print(f"{live.sum()} waves stamped; last callback {'published fresh parameters' if (args.callbacks - 1) % 2 == 0 else 'reused the table'}")
-    for i, nm in enumerate(names):
+    for i, nm in enumerate(names[:6]):
         col = st[:, i]
         ok = col > 0
         if not ok.any():
             continue
         rel = (col[ok] - t0) * 0.01
         print(f"  {i} {nm:20s} min {rel.min():7.2f}  p50 {np.median(rel):7.2f}  p90 {np.percentile(rel, 90):7.2f}  max {rel.max():7.2f} us   ({ok.sum()} waves)")
+    if (st[:, 7] > 0).any():  # shader clock held during the launch: s_memtime cycles per s_memrealtime tick (100 MHz)
+        ok = (st[:, 7] > 0) & (st[:, 5] > 0)
+        mhz = (st[ok, 7] - st[ok, 6]) / np.maximum(st[ok, 5] - st[ok, 0], 1) * 100.0
+        print(f"  shader clock inside the launch: p10 {np.percentile(mhz, 10):.0f}  p50 {np.median(mhz):.0f}  p90 {np.percentile(mhz, 90):.0f} MHz")
+    names = names[:6]
     # per-workgroup spread of the loop end (who the first epilogue barrier waits for)
     wg = np.nonzero(live)[0] // 8
     loop = (st[:, 3] - t0) * 0.01
