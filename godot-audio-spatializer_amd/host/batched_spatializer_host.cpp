@@ -1,43 +1,76 @@
 // batched_spatializer_host.cpp -- see include/gas_amd_host.h.  Plain C++17, no engine, no HIP calls of its
 // own: everything device-side goes through the C ABI (gas_process_block & friends).
+//
+// Threading (the split of audio_spatializer.h:135-138, made explicit):
+//   control threads (main / physics): start_playback*, stop_playback, set_spatializer_parameters,
+//       set_playback_disable_threshold_db, is_playback_active, playback_count -- any number of threads, any time;
+//   audio thread: get_mixed_frames, one caller.
+// The control side never touches the playback list.  It hands work over through an inbox (one mutex, held for a
+// push or a swap -- the role of the reference's parameter mutex, audio_spatializer.cpp:558-574) and flips per-playback
+// atomics (the reference's SafeFlag active, audio_spatializer.h:57-66); the audio thread adopts new playbacks, applies
+// parameters, reaps ended ones and is the ONLY thread that talks to the gas_ctx slot API (alloc / free / draining /
+// bind), which is what include/gas_amd.h asks for.  Reaped nodes are deleted on a control thread (deferred delete,
+// audio_spatializer.cpp:538-547): the audio thread only moves them to a graveyard.
+#include <atomic>
 #include <cmath>
 #include <cstring>
 #include <memory>
+#include <mutex>
 #include <new>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/gas_amd_host.h"
 
 namespace {
 
-constexpr int LOOKAHEAD = GAS_LOOKAHEAD_BUFFER_SIZE;
+constexpr int TAIL = GAS_LOOKAHEAD_BUFFER_SIZE; // frames a playback runs ahead of what the DSP sees (audio_spatializer.h:49)
 
-// audio_spatializer.h:55-66 SpatialPlaybackListNode
-struct PlaybackNode {
-	uint32_t id = 0;
-	uint32_t slot = 0;
-	gas_host_stream_mix_fn mix = nullptr;
-	void *user = nullptr;
-	bool active = true;
-	bool has_frames = true;
-	bool has_params = false;
-	gas_params params{};
-	gas_audio_frame lookahead[LOOKAHEAD]{};
-	bool device_stream = false; // sampled on the GPU (gas_host_start_playback_device_stream)
-	// array-backed stream (gas_host_start_playback_array)
-	const gas_audio_frame *array = nullptr;
-	int64_t array_frames = 0, array_pos = 0;
+// What control threads may look at once a playback has been handed to the audio thread.
+struct Shared {
+	std::atomic<bool> active{ true }; // cleared by stop_playback, by the silence gate, or by a start that failed
 };
 
-int array_mix(void *user, gas_audio_frame *buffer, float /*rate_scale*/, int frames) {
-	PlaybackNode *n = static_cast<PlaybackNode *>(user);
-	int64_t left = n->array_frames - n->array_pos;
-	int m = (int)(left < frames ? (left < 0 ? 0 : left) : frames);
-	std::memcpy(buffer, n->array + n->array_pos, sizeof(gas_audio_frame) * (size_t)m);
-	std::memset(buffer + m, 0, sizeof(gas_audio_frame) * (size_t)(frames - m));
-	n->array_pos += m;
-	return m;
-}
+// One playback.  Built on a control thread, then owned by the audio thread until it is buried.
+struct Playback {
+	uint32_t id = 0;
+	uint32_t slot = 0;
+	bool has_slot = false;
+	std::shared_ptr<Shared> shared;
+	// where its frames come from: a callback (the engine's AudioStreamPlayback::mix), a caller-owned array, or a
+	// device-resident stream the library samples itself
+	gas_host_stream_mix_fn feed = nullptr;
+	void *feed_user = nullptr;
+	const gas_audio_frame *array = nullptr;
+	int64_t array_frames = 0, array_pos = 0;
+	bool on_device = false;
+	uint32_t device_stream = 0;
+	uint64_t device_start = 0;
+	// audio-thread state
+	bool stream_live = true; // the source still has frames (has_frames, audio_spatializer.h:63)
+	bool have_params = false;
+	float pitch_scale = 1.0f;
+	gas_audio_frame tail[TAIL]{}; // the 64 frames sampled ahead last callback
+
+	int pull(gas_audio_frame *dst, int frames) {
+		if (feed) {
+			return feed(feed_user, dst, pitch_scale, frames);
+		}
+		const int64_t left = array_frames - array_pos;
+		const int got = (int)(left < frames ? (left < 0 ? 0 : left) : frames);
+		std::memcpy(dst, array + array_pos, sizeof(gas_audio_frame) * (size_t)got);
+		std::memset(dst + got, 0, sizeof(gas_audio_frame) * (size_t)(frames - got));
+		array_pos += got;
+		return got;
+	}
+};
+
+struct Command {
+	enum Kind { START, PARAMS } kind = START;
+	uint32_t id = 0;
+	std::unique_ptr<Playback> playback; // START
+	gas_params params{}; // PARAMS
+};
 
 // [ENGINE] Math::db_to_linear
 float db_to_linear(float db) {
@@ -50,163 +83,227 @@ struct gas_host {
 	gas_ctx *ctx = nullptr;
 	int kind = 0;
 	std::vector<int32_t> effects;
-	int channel_count = 1; // should_mix_channels ? AudioServer channels : 1 (audio_spatializer.cpp:172-179)
-	int ctx_channels = 1; // rows of the library's [C][F] output
-	bool channel_mixed[GAS_MAX_CHANNELS_PER_BUS] = { true, true, true, true }; // :78-80
-	float disable_threshold_db = -80.0f; // audio_spatializer.h:87
-	uint32_t next_id = 1;
-	// newest first, like SafeList::insert at head
-	std::vector<std::unique_ptr<PlaybackNode>> list;
-	// audio-thread buffers (playback_buffer / mix_buffer, audio_spatializer.h:78-81)
-	std::vector<gas_audio_frame> playback_buffer; // [n + 64]
-	std::vector<gas_audio_frame> rows; // [active][n]
+	int pairs_visible = 1; // should_mix_channels ? AudioServer channel pairs : 1 (audio_spatializer.cpp:172-179)
+	int ctx_pairs = 1; // rows of the library's [C][F] output
+	float fade_env[TAIL]; // end-of-stream ramp, audio_spatializer.cpp:382-392 (same f32 products)
+
+	// ---- shared between threads ----
+	std::atomic<uint32_t> next_id{ 1 };
+	std::atomic<int> node_count{ 0 }; // playbacks started and not yet reaped
+	std::atomic<int> mode{ 0 }; // 0 undecided, 1 callback/array playbacks, 2 device-stream playbacks
+	std::atomic<float> disable_threshold_db{ -80.0f }; // audio_spatializer.h:87
+	std::mutex reg_mu; // id -> shared state, for the control side's lookups
+	std::unordered_map<uint32_t, std::shared_ptr<Shared>> registry;
+	std::mutex inbox_mu; // commands for the audio thread, and the nodes it has finished with
+	std::vector<Command> inbox;
+	std::vector<std::unique_ptr<Playback>> graveyard;
+
+	// ---- audio thread only ----
+	std::vector<std::unique_ptr<Playback>> list; // newest first, like SafeList::insert at head
+	std::unordered_map<uint32_t, Playback *> by_id;
+	std::vector<Command> batch; // the inbox of this callback
+	uint32_t served = 0xFu; // channel pairs handed out since the last mix; all set => the next request mixes (:78-80)
+	std::vector<gas_audio_frame> window; // [n + 64]
+	std::vector<gas_audio_frame> rows; // [playbacks][n]
 	std::vector<uint32_t> slots;
-	std::vector<PlaybackNode *> row_node;
+	std::vector<Playback *> row_owner;
 	std::vector<float> peaks;
-	std::vector<gas_audio_frame> mix_buffer; // [ctx_channels][n]
-	bool mix_valid = false;
-	int mode = 0; // 0 undecided, 1 callback/array playbacks, 2 device-stream playbacks
-	std::vector<uint8_t> has_frames_out;
+	std::vector<uint8_t> live_out;
+	std::vector<gas_audio_frame> mix; // [ctx_pairs][n]
 
-	PlaybackNode *find(uint32_t id) {
-		for (auto &n : list) {
-			if (n->id == id) {
-				return n.get();
-			}
-		}
-		return nullptr;
+	// ---------------------------------------------------------------- control side
+	std::shared_ptr<Shared> lookup(uint32_t id) {
+		std::lock_guard<std::mutex> lk(reg_mu);
+		auto it = registry.find(id);
+		return it == registry.end() ? nullptr : it->second;
 	}
 
-	// audio_spatializer.cpp:367-408
-	void fetch_source(PlaybackNode *pb, gas_audio_frame *buf, int n) {
-		if (pb->has_frames) {
-			for (int i = 0; i < LOOKAHEAD; i++) {
-				buf[i] = pb->lookahead[i];
-			}
-			const float pitch_scale = pb->params.pitch_scale;
-			const int mixed_frames = pb->mix(pb->user, &buf[LOOKAHEAD], pitch_scale, n);
-			if (mixed_frames != n) {
-				float fadeout_base = 0.96f;
-				float fadeout_coefficient = 1;
-				float buffer_size_float = (float)LOOKAHEAD;
-				float buffer_linear_fade_idx = 0.0f;
-				const int fade_limit = mixed_frames + LOOKAHEAD;
-				for (int idx = mixed_frames; idx < n; idx++) {
-					if (idx < fade_limit) {
-						fadeout_coefficient *= fadeout_base;
-						const float f = fadeout_coefficient * (buffer_size_float - buffer_linear_fade_idx) / buffer_size_float;
-						buf[idx].left *= f;
-						buf[idx].right *= f;
-						buffer_linear_fade_idx += 1.0f;
-					} else {
-						buf[idx].left *= 0.0f;
-						buf[idx].right *= 0.0f;
-					}
-				}
-				pb->has_frames = false;
-				// from now on the gate reads this playback's peak (audio_spatializer.cpp:464)
-				gas_source_set_draining(ctx, pb->slot, 1);
-			} else {
-				for (int i = 0; i < LOOKAHEAD; i++) {
-					pb->lookahead[i] = buf[n + i];
-				}
-			}
-		} else {
-			std::memset(buf, 0, sizeof(gas_audio_frame) * (size_t)(n + LOOKAHEAD)); // :407
+	void empty_graveyard() { // node memory is released here, never on the audio thread
+		std::vector<std::unique_ptr<Playback>> dead;
+		{
+			std::lock_guard<std::mutex> lk(inbox_mu);
+			dead.swap(graveyard);
 		}
 	}
 
-	// audio_spatializer.cpp:326-471, one device launch group for all playbacks
-	int mix_from_playback_list(int n) {
-		mix_buffer.assign((size_t)ctx_channels * n, gas_audio_frame{ 0.0f, 0.0f }); // :335-343
-		playback_buffer.resize((size_t)n + LOOKAHEAD);
-		rows.clear();
-		slots.clear();
-		row_node.clear();
-		if (mode == 2) {
-			// device-resident streams: the library samples the windows itself and reports has_frames per row
-			for (auto &up : list) {
-				PlaybackNode *pb = up.get();
-				if (pb->active && pb->has_params) {
-					slots.push_back(pb->slot);
-					row_node.push_back(pb);
-				}
-			}
-			const uint32_t count = (uint32_t)slots.size();
-			peaks.assign((size_t)count * 2 + 2, 0.0f);
-			has_frames_out.assign((size_t)count + 1, 0);
-			const int rc = gas_process_block_streams(ctx, slots.data(), count, (uint32_t)n, mix_buffer.data(), peaks.data(), has_frames_out.data(), GAS_MEM_HOST);
-			if (rc != GAS_OK) {
-				return rc;
-			}
-			const float threshold = db_to_linear(disable_threshold_db);
-			for (uint32_t r = 0; r < count; r++) {
-				PlaybackNode *pb = row_node[r];
-				pb->has_frames = has_frames_out[r] != 0; // audio_spatializer.cpp:398
-				if (!pb->has_frames) { // :464-469
-					const float l = peaks[2 * r], rr = peaks[2 * r + 1];
-					if ((rr > l ? rr : l) <= threshold) {
-						pb->active = false;
-					}
-				}
-			}
-			return GAS_OK;
+	int enqueue_start(std::unique_ptr<Playback> pb, uint32_t *out_id) {
+		pb->id = next_id.fetch_add(1);
+		pb->shared = std::make_shared<Shared>();
+		*out_id = pb->id;
+		{
+			std::lock_guard<std::mutex> lk(reg_mu);
+			registry.emplace(pb->id, pb->shared);
 		}
-		for (auto &up : list) {
-			PlaybackNode *pb = up.get();
-			if (!pb->active) { // :355-357
-				continue;
-			}
-			if (!pb->has_params) { // :330 parameters.is_null(): nothing is mixed for it
-				continue;
-			}
-			fetch_source(pb, playback_buffer.data(), n);
-			rows.insert(rows.end(), playback_buffer.begin(), playback_buffer.begin() + n); // DSP consumes [0, n)
-			slots.push_back(pb->slot);
-			row_node.push_back(pb);
-		}
-		const uint32_t count = (uint32_t)slots.size();
-		peaks.assign((size_t)count * 2 + 2, 0.0f);
-		const int rc = gas_process_block(ctx, rows.data(), slots.data(), count, (uint32_t)n, mix_buffer.data(), peaks.data(), GAS_MEM_HOST);
-		if (rc != GAS_OK) {
-			return rc; // mix_buffer was zero-filled by the library
-		}
-		const float threshold = db_to_linear(disable_threshold_db);
-		for (uint32_t r = 0; r < count; r++) { // :464-469
-			PlaybackNode *pb = row_node[r];
-			if (!pb->has_frames) {
-				const float l = peaks[2 * r], rr = peaks[2 * r + 1];
-				if ((rr > l ? rr : l) <= threshold) {
-					pb->active = false;
-				}
-			}
-		}
+		node_count.fetch_add(1);
+		Command c;
+		c.kind = Command::START;
+		c.id = pb->id;
+		c.playback = std::move(pb);
+		std::lock_guard<std::mutex> lk(inbox_mu);
+		inbox.push_back(std::move(c));
 		return GAS_OK;
 	}
 
-	// audio_spatializer.cpp:473-492
-	void manage_playback_state() {
-		for (size_t i = 0; i < list.size();) {
-			if (!list[i]->active) {
-				gas_source_free(ctx, list[i]->slot); // deferred to the next block boundary by the library
-				list.erase(list.begin() + (long)i);
+	// ---------------------------------------------------------------- audio side
+	void bury(std::unique_ptr<Playback> pb) {
+		pb->shared->active.store(false);
+		{
+			std::lock_guard<std::mutex> lk(reg_mu);
+			registry.erase(pb->id);
+		}
+		node_count.fetch_sub(1);
+		std::lock_guard<std::mutex> lk(inbox_mu);
+		graveyard.push_back(std::move(pb));
+	}
+
+	// New playbacks and parameters queued since the last callback, in the order they were issued.
+	void adopt_inbox() {
+		batch.clear();
+		{
+			std::lock_guard<std::mutex> lk(inbox_mu);
+			batch.swap(inbox);
+		}
+		for (Command &c : batch) {
+			if (c.kind == Command::START) {
+				std::unique_ptr<Playback> pb = std::move(c.playback);
+				// _instantiate_playback_data (audio_spatializer.cpp:69): the device-resident slot
+				int rc = gas_source_alloc(ctx, kind, effects.data(), (uint32_t)effects.size(), &pb->slot);
+				pb->has_slot = rc == GAS_OK;
+				if (rc == GAS_OK && pb->on_device) {
+					rc = gas_source_bind_stream(ctx, pb->slot, pb->device_stream, pb->device_start);
+				}
+				if (rc != GAS_OK) { // out of slots / unknown stream: the playback never becomes audible
+					if (pb->has_slot) {
+						gas_source_free(ctx, pb->slot);
+					}
+					bury(std::move(pb));
+					continue;
+				}
+				// (the reference marks every channel pair "mixed" when the first playback starts, :78-80, so that the next
+				// request mixes; here a playback is only ever adopted inside the request that starts a new mix)
+				by_id[pb->id] = pb.get();
+				list.insert(list.begin(), std::move(pb)); // head insertion
 			} else {
-				i++;
+				auto it = by_id.find(c.id);
+				if (it == by_id.end()) {
+					continue; // reaped meanwhile
+				}
+				Playback *pb = it->second;
+				pb->pitch_scale = c.params.pitch_scale;
+				pb->have_params = true;
+				gas_params_publish(ctx, pb->slot, &c.params); // snapshotted by this callback's gas_process_block (:328)
+			}
+		}
+		batch.clear();
+	}
+
+	// The window the DSP sees: last callback's 64-frame tail, then fresh frames (audio_spatializer.cpp:367-378).  When
+	// the source runs dry inside it, the 64 frames after its last one ramp down and the rest is blanked (:380-398);
+	// a multiply by zero keeps a NaN a NaN, as the reference's `*= 0.0` does.
+	void build_window(Playback *pb, gas_audio_frame *w, int n) {
+		if (!pb->stream_live) {
+			std::memset(w, 0, sizeof(gas_audio_frame) * (size_t)(n + TAIL)); // effect tails ring out on silence (:405-408)
+			return;
+		}
+		std::memcpy(w, pb->tail, sizeof(pb->tail));
+		const int got = pb->pull(w + TAIL, n);
+		if (got == n) {
+			std::memcpy(pb->tail, w + n, sizeof(pb->tail));
+			return;
+		}
+		const int ramp_end = got + TAIL < n ? got + TAIL : n;
+		for (int i = got; i < ramp_end; i++) {
+			w[i].left *= fade_env[i - got];
+			w[i].right *= fade_env[i - got];
+		}
+		for (int i = ramp_end; i < n; i++) {
+			w[i].left *= 0.0f;
+			w[i].right *= 0.0f;
+		}
+		pb->stream_live = false;
+		gas_source_set_draining(ctx, pb->slot, 1); // from now on the gate reads this playback's peak (:464)
+	}
+
+	// The silence gate (audio_spatializer.cpp:464-469) over the peaks the library returned.
+	void gate(uint32_t count) {
+		const float threshold = db_to_linear(disable_threshold_db.load());
+		for (uint32_t r = 0; r < count; r++) {
+			Playback *pb = row_owner[r];
+			if (pb->stream_live) {
+				continue;
+			}
+			const float l = peaks[2 * r], rr = peaks[2 * r + 1];
+			if ((rr > l ? rr : l) <= threshold) {
+				pb->shared->active.store(false);
 			}
 		}
 	}
 
-	// audio_spatializer.cpp:494-508
-	bool check_channel_mixed(int channel) {
-		if (channel_mixed[channel]) {
-			for (bool &m : channel_mixed) {
-				m = false;
-			}
-			channel_mixed[channel] = true;
-			return true;
+	// audio_spatializer.cpp:326-471 with ONE device launch group for all playbacks
+	int mix_all(int n) {
+		mix.assign((size_t)ctx_pairs * n, gas_audio_frame{ 0.0f, 0.0f }); // :335-343
+		rows.clear();
+		slots.clear();
+		row_owner.clear();
+		const bool device_streams = mode.load() == 2;
+		if (!device_streams) {
+			window.resize((size_t)n + TAIL);
 		}
-		channel_mixed[channel] = true;
-		return false;
+		for (auto &up : list) {
+			Playback *pb = up.get();
+			if (!pb->shared->active.load() || !pb->have_params) { // :355-357; :330 parameters.is_null(): nothing is mixed
+				continue;
+			}
+			if (!device_streams) {
+				build_window(pb, window.data(), n);
+				rows.insert(rows.end(), window.begin(), window.begin() + n); // the DSP consumes [0, n)
+			}
+			slots.push_back(pb->slot);
+			row_owner.push_back(pb);
+		}
+		const uint32_t count = (uint32_t)slots.size();
+		peaks.assign((size_t)count * 2 + 2, 0.0f);
+		int rc;
+		if (device_streams) { // the library samples the windows itself and reports has_frames per row
+			live_out.assign((size_t)count + 1, 0);
+			rc = gas_process_block_streams(ctx, slots.data(), count, (uint32_t)n, mix.data(), peaks.data(), live_out.data(), GAS_MEM_HOST);
+			if (rc == GAS_OK) {
+				for (uint32_t r = 0; r < count; r++) {
+					row_owner[r]->stream_live = live_out[r] != 0; // audio_spatializer.cpp:398
+				}
+			}
+		} else {
+			rc = gas_process_block(ctx, rows.data(), slots.data(), count, (uint32_t)n, mix.data(), peaks.data(), GAS_MEM_HOST);
+		}
+		if (rc != GAS_OK) {
+			return rc; // the library zero-filled the mix
+		}
+		gate(count);
+		return GAS_OK;
+	}
+
+	// audio_spatializer.cpp:473-492: inactive playbacks leave the list; their slot is freed at the next block boundary
+	void reap() {
+		for (size_t i = 0; i < list.size();) {
+			if (list[i]->shared->active.load()) {
+				i++;
+				continue;
+			}
+			std::unique_ptr<Playback> pb = std::move(list[i]);
+			list.erase(list.begin() + (long)i);
+			by_id.erase(pb->id);
+			gas_source_free(ctx, pb->slot);
+			bury(std::move(pb));
+		}
+	}
+
+	// audio_spatializer.cpp:494-508 as a bit set: a pair that was already handed out since the last mix starts a new
+	// callback (and is the only one handed out so far); otherwise it is just marked.
+	bool starts_new_callback(int channel) {
+		const uint32_t bit = 1u << channel;
+		const bool again = (served & bit) != 0;
+		served = again ? bit : (served | bit);
+		return again;
 	}
 };
 
@@ -235,151 +332,131 @@ int gas_host_create(gas_ctx *ctx, int kind, const int32_t *effects, uint32_t n_e
 	}
 	h->ctx = ctx;
 	h->kind = kind;
-	h->ctx_channels = (int)cfg.channel_count;
-	h->channel_count = kind == GAS_KIND_3D_MIX ? (int)cfg.channel_count : 1;
+	h->ctx_pairs = (int)cfg.channel_count;
+	h->pairs_visible = kind == GAS_KIND_3D_MIX ? (int)cfg.channel_count : 1;
 	h->effects.assign(effects, effects + n_effects);
+	// ramp k = 0.96^(k+1) * (64 - k) / 64, built with the reference's f32 operations in its order
+	float coefficient = 1.0f, step = 0.0f;
+	for (int k = 0; k < TAIL; k++) {
+		coefficient *= 0.96f;
+		h->fade_env[k] = coefficient * ((float)TAIL - step) / (float)TAIL;
+		step += 1.0f;
+	}
 	*out_host = h;
 	return GAS_OK;
 }
 
-void gas_host_destroy(gas_host *h) {
+void gas_host_destroy(gas_host *h) { // no thread may be inside the host any more
 	if (!h) {
 		return;
 	}
-	for (auto &n : h->list) {
-		gas_source_free(h->ctx, n->slot);
+	for (auto &pb : h->list) {
+		gas_source_free(h->ctx, pb->slot);
 	}
 	delete h;
+}
+
+static int start_common(gas_host *h, std::unique_ptr<Playback> pb, int want_mode, uint32_t *out_id) {
+	int undecided = 0;
+	if (!h->mode.compare_exchange_strong(undecided, want_mode) && undecided != want_mode) {
+		return GAS_ERR_KIND_MISMATCH; // a host serves callback/array playbacks or device streams, not both
+	}
+	h->empty_graveyard();
+	return h->enqueue_start(std::move(pb), out_id);
 }
 
 int gas_host_start_playback(gas_host *h, gas_host_stream_mix_fn mix, void *user, uint32_t *out_id) {
 	if (!h || !mix || !out_id) {
 		return GAS_ERR_INVALID_ARGUMENT;
 	}
-	if (h->mode == 2) {
-		return GAS_ERR_KIND_MISMATCH;
-	}
-	h->mode = 1;
-	std::unique_ptr<PlaybackNode> n(new (std::nothrow) PlaybackNode());
-	if (!n) {
+	std::unique_ptr<Playback> pb(new (std::nothrow) Playback());
+	if (!pb) {
 		return GAS_ERR_OUT_OF_MEMORY;
 	}
-	int rc = gas_source_alloc(h->ctx, h->kind, h->effects.data(), (uint32_t)h->effects.size(), &n->slot);
-	if (rc != GAS_OK) {
-		return rc;
-	}
-	n->id = h->next_id++;
-	n->mix = mix;
-	n->user = user;
-	*out_id = n->id;
-	if (h->list.empty()) { // first playback: every channel marked mixed so the next request remixes (:78-80)
-		for (bool &m : h->channel_mixed) {
-			m = true;
-		}
-	}
-	h->list.insert(h->list.begin(), std::move(n)); // head insertion
-	return GAS_OK;
+	pb->feed = mix;
+	pb->feed_user = user;
+	return start_common(h, std::move(pb), 1, out_id);
 }
 
 int gas_host_start_playback_array(gas_host *h, const gas_audio_frame *stream, int64_t stream_frames, uint32_t *out_id) {
-	if (!stream || stream_frames < 0) {
+	if (!h || !out_id || !stream || stream_frames < 0) {
 		return GAS_ERR_INVALID_ARGUMENT;
 	}
-	int rc = gas_host_start_playback(h, array_mix, nullptr, out_id);
-	if (rc != GAS_OK) {
-		return rc;
+	std::unique_ptr<Playback> pb(new (std::nothrow) Playback());
+	if (!pb) {
+		return GAS_ERR_OUT_OF_MEMORY;
 	}
-	PlaybackNode *n = h->list.front().get();
-	n->user = n;
-	n->array = stream;
-	n->array_frames = stream_frames;
-	return GAS_OK;
+	pb->array = stream;
+	pb->array_frames = stream_frames;
+	return start_common(h, std::move(pb), 1, out_id);
 }
 
 int gas_host_start_playback_device_stream(gas_host *h, uint32_t stream, uint64_t start_frame, uint32_t *out_id) {
 	if (!h || !out_id) {
 		return GAS_ERR_INVALID_ARGUMENT;
 	}
-	if (h->mode == 1) {
-		return GAS_ERR_KIND_MISMATCH;
-	}
-	std::unique_ptr<PlaybackNode> n(new (std::nothrow) PlaybackNode());
-	if (!n) {
+	std::unique_ptr<Playback> pb(new (std::nothrow) Playback());
+	if (!pb) {
 		return GAS_ERR_OUT_OF_MEMORY;
 	}
-	int rc = gas_source_alloc(h->ctx, h->kind, h->effects.data(), (uint32_t)h->effects.size(), &n->slot);
-	if (rc != GAS_OK) {
-		return rc;
-	}
-	rc = gas_source_bind_stream(h->ctx, n->slot, stream, start_frame);
-	if (rc != GAS_OK) {
-		gas_source_free(h->ctx, n->slot);
-		return rc;
-	}
-	h->mode = 2;
-	n->id = h->next_id++;
-	n->device_stream = true;
-	*out_id = n->id;
-	if (h->list.empty()) {
-		for (bool &m : h->channel_mixed) {
-			m = true;
-		}
-	}
-	h->list.insert(h->list.begin(), std::move(n));
-	return GAS_OK;
+	pb->on_device = true;
+	pb->device_stream = stream;
+	pb->device_start = start_frame;
+	return start_common(h, std::move(pb), 2, out_id);
 }
 
 int gas_host_stop_playback(gas_host *h, uint32_t id) {
-	PlaybackNode *n = h ? h->find(id) : nullptr;
-	if (!n) {
+	std::shared_ptr<Shared> s = h ? h->lookup(id) : nullptr;
+	if (!s) {
 		return GAS_ERR_BAD_SLOT;
 	}
-	n->active = false;
+	s->active.store(false); // the audio thread reaps it (audio_spatializer.cpp:98-113, :473-482)
 	return GAS_OK;
 }
 
 int gas_host_set_spatializer_parameters(gas_host *h, uint32_t id, const gas_params *params) {
-	PlaybackNode *n = h ? h->find(id) : nullptr;
-	if (!n || !params) {
-		return n ? GAS_ERR_INVALID_ARGUMENT : GAS_ERR_BAD_SLOT;
+	if (!h || !h->lookup(id)) {
+		return GAS_ERR_BAD_SLOT;
 	}
-	n->params = *params;
-	n->has_params = true;
-	return gas_params_publish(h->ctx, n->slot, params);
+	if (!params) {
+		return GAS_ERR_INVALID_ARGUMENT;
+	}
+	Command c;
+	c.kind = Command::PARAMS;
+	c.id = id;
+	c.params = *params;
+	std::lock_guard<std::mutex> lk(h->inbox_mu);
+	h->inbox.push_back(std::move(c));
+	return GAS_OK;
 }
 
 void gas_host_set_playback_disable_threshold_db(gas_host *h, float db) {
 	if (h) {
-		h->disable_threshold_db = db;
+		h->disable_threshold_db.store(db);
 	}
 }
 
 int gas_host_is_playback_active(gas_host *h, uint32_t id) {
-	PlaybackNode *n = h ? h->find(id) : nullptr;
-	return n && n->active ? 1 : 0;
+	std::shared_ptr<Shared> s = h ? h->lookup(id) : nullptr;
+	return s && s->active.load() ? 1 : 0;
 }
 
 int gas_host_playback_count(gas_host *h) {
-	return h ? (int)h->list.size() : 0;
+	return h ? h->node_count.load() : 0;
 }
 
 void gas_host_bus_map(int should_mix_channels, int channel, const float bus_volume[GAS_MAX_CHANNELS_PER_BUS][2], const float mix_volumes[GAS_MAX_CHANNELS_PER_BUS][2], float out[GAS_MAX_CHANNELS_PER_BUS][2]) {
 	for (int c = 0; c < GAS_MAX_CHANNELS_PER_BUS; c++) {
-		if (should_mix_channels) { // audio_spatializer.cpp:295-313
-			float left = 0.0f, right = 0.0f;
-			if (c == channel) {
-				if (mix_volumes[c][0] > 0.0) {
-					left = bus_volume[c][0] / mix_volumes[c][0];
-				}
-				if (mix_volumes[c][1] > 0.0) {
-					right = bus_volume[c][1] / mix_volumes[c][1];
-				}
+		for (int ear = 0; ear < 2; ear++) {
+			float f;
+			if (!should_mix_channels) {
+				f = mix_volumes[c][ear]; // audio_spatializer.cpp:314-318: AudioServer applies the mix volume
+			} else if (c == channel && mix_volumes[c][ear] > 0.0) {
+				f = bus_volume[c][ear] / mix_volumes[c][ear]; // :295-313: the mix volume is in the frames already
+			} else {
+				f = 0.0f;
 			}
-			out[c][0] = left;
-			out[c][1] = right;
-		} else { // :314-318
-			out[c][0] = mix_volumes[c][0];
-			out[c][1] = mix_volumes[c][1];
+			out[c][ear] = f;
 		}
 	}
 }
@@ -391,23 +468,22 @@ int gas_host_get_mixed_frames(gas_host *h, int channel, gas_audio_frame *frames,
 	if (channel < 0 || channel >= GAS_MAX_CHANNELS_PER_BUS) {
 		return GAS_ERR_BAD_CHANNEL;
 	}
-	if (h->check_channel_mixed(channel)) {
-		const int rc = h->mix_from_playback_list(frame_count);
-		h->manage_playback_state();
-		h->mix_valid = rc == GAS_OK;
+	if (h->starts_new_callback(channel)) {
+		h->adopt_inbox();
+		const int rc = h->mix_all(frame_count);
+		h->reap();
 		if (rc != GAS_OK) {
 			std::memset(frames, 0, sizeof(gas_audio_frame) * (size_t)frame_count);
 			return rc;
 		}
 	}
-	const int visible = h->kind == GAS_KIND_3D_MIX ? h->channel_count : 1;
-	if (channel >= visible) {
+	if (channel >= h->pairs_visible) {
 		return GAS_ERR_BAD_CHANNEL; // :521
 	}
-	if ((size_t)frame_count * h->ctx_channels != h->mix_buffer.size()) {
+	if ((size_t)frame_count * h->ctx_pairs != h->mix.size()) {
 		return GAS_ERR_FRAME_COUNT; // :522
 	}
-	std::memcpy(frames, h->mix_buffer.data() + (size_t)channel * frame_count, sizeof(gas_audio_frame) * (size_t)frame_count);
+	std::memcpy(frames, h->mix.data() + (size_t)channel * frame_count, sizeof(gas_audio_frame) * (size_t)frame_count);
 	return GAS_OK;
 }
 

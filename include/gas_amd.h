@@ -14,7 +14,9 @@
  *   - gas_params_publish*  : physics thread, may run concurrently with the audio thread.
  *   - gas_process_block, gas_process_frames_1, gas_mix_channel_1 : audio thread only,
  *     one caller at a time, never re-entrant per context.
- *   - everything else      : main thread, not concurrently with the audio thread.
+ *   - everything else      : one thread at a time and not concurrently with the audio-thread entries -- the main
+ *     thread while audio is stopped, or the audio thread itself between callbacks (what gas_amd_host.h's host layer
+ *     does for slot alloc / free / draining / stream binding, so that start/stop from other threads never race).
  */
 #ifndef GAS_AMD_H
 #define GAS_AMD_H

@@ -8,6 +8,20 @@
  * gas_process_block for all playbacks where the reference loops process_frames / mix_channel per playback.
  * In a Godot build the same class sits behind AudioStreamPlaybackSpatial::mix; here the
  * engine's AudioStreamPlayback::mix is a plain callback.
+ *
+ * Threading contract (the reference's split, audio_spatializer.h:135-138, with its SafeList / SafeFlag / Mutex roles):
+ *   - control entries -- gas_host_start_playback*, gas_host_stop_playback, gas_host_set_spatializer_parameters,
+ *     gas_host_set_playback_disable_threshold_db, gas_host_is_playback_active, gas_host_playback_count -- may be
+ *     called from any number of threads (main, physics) at any time, concurrently with the audio thread.  They only
+ *     queue commands / flip per-playback atomics; a start or a parameter set takes effect at the top of the next
+ *     callback, in the order issued (one parameter snapshot per callback, audio_spatializer.cpp:328).
+ *   - gas_host_get_mixed_frames is the audio thread: one caller.  It is the only thread that uses the context's slot
+ *     API (gas_source_alloc / free / set_draining / bind_stream) and gas_process_block, as gas_amd.h requires; a start
+ *     that cannot get a slot (or names an unknown device stream) simply never becomes active.
+ *   - nodes are deleted on a control thread (deferred delete, audio_spatializer.cpp:538-547); the stream callback of a
+ *     playback is only ever invoked from the audio thread.
+ *   - gas_host_create / gas_host_destroy: no other thread inside the host.
+ * tests/test_host_tsan.py runs this contract under ThreadSanitizer.
  */
 #ifndef GAS_AMD_HOST_H
 #define GAS_AMD_HOST_H

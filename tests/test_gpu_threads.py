@@ -89,3 +89,60 @@ def test_alloc_free_between_callbacks(gas):
                 s = ctx.source_alloc(K.KIND_3D_MIX)
                 ctx.params_publish(s, synth.draw_params(rng, 1)[0])
                 live.append(s)
+
+
+def test_host_layer_start_stop_params_from_another_thread(gas):
+    """include/gas_amd_host.h's threading contract on the GPU: a control thread starts, re-parameterises and stops
+    playbacks while the audio thread keeps calling get_mixed_frames.  Nothing may crash, every callback must succeed,
+    and once everything was stopped the list must drain to zero.  (The race-freedom proof proper is the CPU
+    ThreadSanitizer run, tests/test_host_tsan.py; this checks the same entries against the real library.)"""
+    from godot_audio_spatializer_amd import synth
+
+    K = gas.capi
+    F = 512
+    rng = np.random.default_rng(3)
+    hrir = synth.synthetic_hrir(rng, dirs=8)
+    with gas.SpatializerContext(max_sources=64, frames=F, flags=K.FLAG_PEAKS_DRAINING_ONLY) as ctx:
+        ctx.hrtf_load(hrir)
+        host = K.BatchedSpatializerHost(ctx, K.KIND_EFFECT, (K.FX_HRTF,))
+        streams = [rng.uniform(-0.5, 0.5, (F * 3 + 100 * i, 2)).astype(np.float32) for i in range(8)]
+        params = synth.draw_params(rng, 8, dirs=8)
+        stop = threading.Event()
+        errors = []
+        started = []
+
+        def control():
+            try:
+                ids = []
+                for r in range(120):
+                    pid = host.start_playback_array(streams[r % 8])
+                    host.set_spatializer_parameters(pid, params[r % 8])
+                    ids.append(pid)
+                    started.append(pid)
+                    if len(ids) > 12:
+                        host.stop_playback(ids.pop(0))
+                    for q in ids[-4:]:
+                        host.set_spatializer_parameters(q, params[(r + q) % 8])
+                        host.is_playback_active(q)
+                    host.playback_count()
+                for q in ids:
+                    host.stop_playback(q)
+            except Exception as e:  # pragma: no cover
+                errors.append(e)
+            finally:
+                stop.set()
+
+        t = threading.Thread(target=control)
+        t.start()
+        n_cb = 0
+        while not stop.is_set() or host.playback_count() > 0:
+            rc, out = host.get_mixed_frames(0, F)
+            assert rc == 0
+            assert np.isfinite(out).all()
+            n_cb += 1
+            assert n_cb < 200000
+        t.join()
+        assert not errors, errors
+        assert len(started) == 120 and host.playback_count() == 0
+        assert not any(host.is_playback_active(p) for p in started)
+        host.close()
