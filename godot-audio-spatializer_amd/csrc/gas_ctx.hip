@@ -628,17 +628,34 @@ int flush_params(gas_ctx *c) {
 	return GAS_OK;
 }
 
+void stream_rows_sync_back(gas_ctx *c);
+
 int apply_pending_frees(gas_ctx *c) {
+	if (c->pending_free.empty()) {
+		return GAS_OK;
+	}
+	bool had_stream = false;
+	for (uint32_t s : c->pending_free) {
+		had_stream = had_stream || c->h_cursors[s].pcm != nullptr;
+	}
+	if (had_stream) {
+		stream_rows_sync_back(c); // the compact mirror may still name these slots: fold it back before they are cleared
+		c->stream_groups_gen = UINT64_MAX;
+	}
 	for (uint32_t s : c->pending_free) {
 		SlotInfo &si = c->slots[s];
 		si = SlotInfo{};
 		si.dirty_state = 1;
 		c->free_list.push_back(s);
+		if (c->h_cursors[s].pcm) {
+			// a freed playback lets go of its stream (gas_stream_destroy must not see it as bound for ever, and a
+			// re-allocated slot must not inherit the cursor): host mirror and device cursor both
+			c->h_cursors[s] = gas_cursor{};
+			GAS_HIP(c, hipMemsetAsync(c->d_cursors + s, 0, sizeof(gas_cursor), c->stream));
+		}
 	}
-	if (!c->pending_free.empty()) {
-		c->pending_free.clear();
-		c->cached_n = UINT32_MAX;
-	}
+	c->pending_free.clear();
+	c->cached_n = UINT32_MAX;
 	return GAS_OK;
 }
 
@@ -1279,7 +1296,6 @@ int gas_calc_spatialization_areas(gas_ctx *c, const gas_spatializer3d_config *cf
 	return GAS_OK;
 }
 
-static void stream_rows_sync_back(gas_ctx *c);
 static inline void stream_rows_sync_back_fwd(gas_ctx *c) {
 	stream_rows_sync_back(c);
 }
@@ -1360,8 +1376,11 @@ int gas_source_bind_stream(gas_ctx *c, uint32_t slot, uint32_t stream, uint64_t 
 	return GAS_OK;
 }
 
+} // extern "C"
+
+namespace {
 // Write the compact per-row mirror of the cached stream list back into the per-slot cursors.
-static void stream_rows_sync_back(gas_ctx *c) {
+void stream_rows_sync_back(gas_ctx *c) {
 	for (size_t i = 0; i < c->stream_rows.size(); i++) {
 		gas_cursor &cur = c->h_cursors[c->stream_slots_host[i]];
 		const gas_ctx::StreamRow &r = c->stream_rows[i];
@@ -1372,6 +1391,9 @@ static void stream_rows_sync_back(gas_ctx *c) {
 	}
 	c->stream_rows.clear();
 }
+} // namespace
+
+extern "C" {
 
 int gas_process_block_streams(gas_ctx *c, const uint32_t *slots, uint32_t n, uint32_t frames, gas_audio_frame *out, float *peaks, uint8_t *has_frames, int mem) {
 	if (!c || !out || (n > 0 && !slots) || n > c->cfg.max_sources || (mem != GAS_MEM_HOST && mem != GAS_MEM_DEVICE)) {
@@ -1401,6 +1423,27 @@ int gas_process_block_streams(gas_ctx *c, const uint32_t *slots, uint32_t n, uin
 			}
 			if (c->slots[slots[i]].has_params && c->h_params[slots[i]].pitch_scale != 1.0f && c->h_params[slots[i]].pitch_scale != 0.0f) {
 				return fail(GAS_ERR_UNSUPPORTED_CHAIN); // the device sampler does not resample (the host path does)
+			}
+		}
+		// Everything gas_process_block could still reject is checked BEFORE a cursor moves: the reference consumes a
+		// playback's frames only when it mixes them (audio_spatializer.cpp:378), so a failed callback must leave
+		// the playback cursors (host mirror and device) where they were.
+		if (++c->stamp_gen == 0) {
+			std::fill(c->stamp.begin(), c->stamp.end(), 0u);
+			c->stamp_gen = 1;
+		}
+		for (uint32_t i = 0; i < n; i++) {
+			const SlotInfo &si = c->slots[slots[i]];
+			if (!si.has_params) {
+				return fail(GAS_ERR_NO_PARAMS);
+			}
+			if (c->stamp[slots[i]] == c->stamp_gen) {
+				return fail(GAS_ERR_INVALID_ARGUMENT); // one playback twice in a callback
+			}
+			c->stamp[slots[i]] = c->stamp_gen;
+			const bool wants_hrtf = si.group == G_FX_HRTF || si.group == G_FX_ER_HRTF || (si.group == G_FX_GENERIC && chain_has(si.chain_sig, GAS_FX_HRTF));
+			if (wants_hrtf && c->tab.spec == nullptr) {
+				return fail(GAS_ERR_NO_HRTF);
 			}
 		}
 		c->stream_params_touched = false;

@@ -225,7 +225,9 @@ __global__ __launch_bounds__(256) void k_calc_spatialization(const gas_spatializ
 		float db_att = (float)((1.0 - (1.0 < (double)multiplier ? 1.0 : (double)multiplier)) * (double)cfg.attenuation_filter_db); // :376
 		if (cfg.emission_angle_enabled) { // :378-385
 			const float c = v3_dot(v3_normalized(rel), v3_normalized(V3{ s.forward[0], s.forward[1], s.forward[2] }));
-			const float angle = acosf(c) * (float)(180.0 / 3.14159265358979323846);
+			// [ENGINE] Math::acos clamps its argument (recollection, unpinned): a dot of two normalised f32 vectors can land
+			// 1 ulp outside [-1, 1], where the bare libm call returns NaN and the cone test below would silently pass
+			const float angle = (c < -1.0f ? 3.14159265358979323846f : (c > 1.0f ? 0.0f : acosf(c))) * (float)(180.0 / 3.14159265358979323846);
 			if (angle > cfg.emission_angle) {
 				db_att -= -cfg.emission_angle_filter_attenuation_db;
 			}

@@ -1016,7 +1016,8 @@ int gaso_calc_spatialization_area(const gaso_spat3d_config *cfg, const gaso_sour
 		if (cfg->emission_angle_enabled) { /* :378-385 */
 			v3 fw = { s->forward[0], s->forward[1], s->forward[2] };
 			float c = v3_dot(v3_normalized(rel), v3_normalized(fw));
-			float angle = acosf(c) * (float)(180.0 / 3.14159265358979323846);
+			/* [ENGINE] Math::acos clamps: x < -1 -> pi, x > 1 -> 0 (recollection of the engine source, unpinned) */
+			float angle = (c < -1.0f ? 3.14159265358979323846f : (c > 1.0f ? 0.0f : acosf(c))) * (float)(180.0 / 3.14159265358979323846);
 			if (angle > cfg->emission_angle) {
 				db_att -= -cfg->emission_angle_filter_attenuation_db;
 			}

@@ -111,3 +111,61 @@ def test_device_sampler_rejects_pitch_shift(gas):
         with pytest.raises(gas.GasError) as ei:
             ctx.process_block_streams([slot])
         assert ei.value.status == -6
+
+
+def test_freed_playback_releases_its_stream(gas):
+    """A playback bound to a device stream that ended and was freed must not keep the stream "bound" for ever
+    (gas_stream_destroy), and the re-allocated slot must not inherit its cursor."""
+    K = gas.capi
+    F = 512
+    ramp = np.arange(1, 1201, dtype=np.float32) / 4096.0
+    with gas.SpatializerContext(max_sources=1, frames=F) as ctx:
+        sid = ctx.stream_create(ramp)
+        slot = ctx.source_alloc(K.KIND_EFFECT)
+        ctx.params_publish(slot, np.zeros(1, K.PARAMS_DTYPE))
+        ctx.source_bind_stream(slot, sid)
+        hf = [True]
+        for _ in range(6):  # play to the end and past it
+            _, _, hf = ctx.process_block_streams([slot])
+        assert not hf[0]
+        ctx.source_free(slot)  # deferred: takes effect at the next block boundary
+        mix, _, _ = ctx.process_block_streams([])
+        assert not mix.any()
+        ctx.stream_destroy(sid)  # no longer bound
+        again = ctx.source_alloc(K.KIND_EFFECT)
+        assert again == slot
+        ctx.params_publish(again, np.zeros(1, K.PARAMS_DTYPE))
+        mix, _, hf = ctx.process_block_streams([again])  # fresh slot, nothing bound: silence, no stale cursor
+        assert not hf[0] and not mix.any()
+
+
+def test_failed_streams_callback_consumes_no_frames(gas, ob):
+    """The reference consumes a playback's frames only when it mixes them (audio_spatializer.cpp:378): a streams
+    callback that fails (here: HRTF playbacks before gas_hrtf_load) must leave every cursor where it was, so that the
+    first successful callback starts at frame 0."""
+    from godot_audio_spatializer_amd import synth
+
+    K = gas.capi
+    F = 512
+    rng = np.random.default_rng(5)
+    hrir = synth.synthetic_hrir(np.random.default_rng(7), dirs=8)
+    pcms = [(rng.uniform(-0.5, 0.5, 2500) * 32767).astype(np.int16), (rng.uniform(-0.5, 0.5, (1800, 2)) * 32767).astype(np.int16)]
+    floats = [to_float_stereo(p) for p in pcms]
+    params = synth.draw_params(rng, 2, dirs=8)
+    with gas.SpatializerContext(max_sources=2, frames=F) as ctx:
+        slots = ctx.source_alloc_many(2, K.KIND_EFFECT, (K.FX_HRTF,))
+        ctx.params_publish_batch(slots, params)
+        for s, p in zip(slots, pcms):
+            ctx.source_bind_stream(s, ctx.stream_create(p))
+        for _ in range(2):
+            with pytest.raises(gas.GasError) as ei:
+                ctx.process_block_streams(slots)
+            assert ei.value.status == -5  # GAS_ERR_NO_HRTF
+        ctx.hrtf_load(hrir)
+        rig = Rig(ob, ob.KIND_EFFECT, floats, F, chain=(ob.FX_HRTF,), hrir=hrir)
+        rig.params[:] = params.astype(ob.PARAMS_DTYPE)
+        for cb in range(4):
+            got, _, hf = ctx.process_block_streams(slots)
+            rc, want = rig.get_mixed_frames(0)
+            assert rc == 0 and mix_matches(got[0], want), f"callback {cb}"
+            assert [bool(x) for x in hf] == [bool(p.has_frames) for p in rig.pbs]

@@ -80,6 +80,29 @@ def test_stereo_pan_and_attenuation_closed_form(model, pos):
     assert out["update_parameters"][0] == 1 and out["pitch_scale"][0] == 1.0
 
 
+@pytest.mark.parametrize("forward,behind", [((0.0, 0.0, 1.0), True), ((0.0, 0.0, -1.0), False), ((1e-4, 0.0, 3.0), True), ((0.6, 0.0, -0.8), False)])
+def test_emission_cone_on_the_axis(forward, behind):
+    """audio_spatializer_3d.cpp:378-385: angle = rad_to_deg(Math::acos(dot)) between listener->source and the player's
+    +z column.  With the listener exactly on that axis the f32 dot can land 1 ulp outside [-1, 1]; the engine's acos
+    clamps (pi / 0), so a listener straight behind the emitter (angle 180 deg > emission_angle) IS attenuated and one
+    straight in front (0 deg) is not -- a bare acosf would give NaN and skip the attenuation in both cases."""
+    cfg = _cfg(attenuation_model=3, emission_angle_enabled=1, emission_angle=45.0, emission_angle_filter_attenuation_db=-12.0, attenuation_filter_db=-24.0, max_distance=0.0)
+    pose = _pose((0.0, 0.0, -7.0))
+    # listener at the origin: listener->source = (0, 0, -1); `forward` is the player's basis column 2
+    f = np.float32(forward)
+    pose["forward"] = f
+    out = np.zeros(1, ob.PARAMS_DTYPE)
+    ob.calc_spatialization(cfg, None, pose, _listener(), np.zeros(1, np.int32), out)
+    rel = np.float64([0.0, 0.0, -1.0])
+    c = float(np.dot(rel, np.float64(f) / np.linalg.norm(np.float64(f))))
+    angle = np.degrees(np.arccos(np.clip(c, -1.0, 1.0)))
+    assert (angle > 45.0) == behind
+    # attenuation model 3 (disabled): multiplier 1 -> db_att = 0, minus the cone attenuation when outside the cone
+    want = _db_to_linear(-12.0 if behind else 0.0)
+    assert np.isfinite(out["linear_attenuation"][0])
+    np.testing.assert_allclose(out["linear_attenuation"][0], want, rtol=2e-6)
+
+
 def test_max_distance_cut_taper_and_latch():
     cfg = _cfg(attenuation_model=0, unit_size=10.0, max_distance=20.0)
     lis = _listener()
