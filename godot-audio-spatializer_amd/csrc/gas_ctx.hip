@@ -173,6 +173,7 @@ struct gas_ctx {
 	uint64_t prof_bytes = 0;
 	int prof_group = -1;
 	bool prof_uni = false; // the timed launch was k_hrtf_uni
+	bool prof_pipe = false; // the timed launch was k_biquad_pipe
 	double ev_overhead_ms = 0.0; // marker/dispatch overhead of an event pair around one launch (calibrated)
 	uint32_t prof_every = 1, prof_tick = 0; // bracket every Nth callback's dominant launch
 
@@ -570,6 +571,7 @@ int run_groups(gas_ctx *c, const gas_audio_frame *d_src, const uint32_t *d_slots
 			}
 			c->prof_group = gt;
 			c->prof_uni = gt == G_FX_HRTF && uni_hrtf && groups[G_FX_HRTF_PK].count == 0;
+			c->prof_pipe = (gt == G_3D_MIX || gt == G_3D_PROCESS || gt == G_FX_SHELF) && gas_biquad_uses_pipe(gt == G_FX_SHELF ? GAS_MODE_FX_HIGHSHELF : (force_mode >= 0 ? force_mode : (gt == G_3D_MIX ? GAS_MODE_MIX_CHANNEL : GAS_MODE_PROCESS_FRAMES)), gr.count, gt == G_3D_MIX ? channel_count : 1, F, false);
 		}
 		p_off += pcount[gt];
 	}
@@ -1897,7 +1899,11 @@ int gas_profile_read(gas_ctx *c, gas_profile *out, int reset) {
 	out->kernel_ms = c->prof_ms;
 	out->bytes_per_launch = c->prof_bytes;
 	if (c->prof_group >= 0) {
-		std::strncpy(out->kernel_name, c->prof_uni ? "k_hrtf_uni" : k_group_kernel[c->prof_group], sizeof(out->kernel_name) - 1);
+		std::string name = c->prof_uni ? "k_hrtf_uni" : k_group_kernel[c->prof_group];
+		if (c->prof_pipe && name.rfind("k_biquad_mix", 0) == 0) {
+			name = "k_biquad_pipe" + name.substr(12);
+		}
+		std::strncpy(out->kernel_name, name.c_str(), sizeof(out->kernel_name) - 1);
 	}
 	if (reset) {
 		c->prof_launches = 0;

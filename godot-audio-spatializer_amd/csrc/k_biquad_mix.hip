@@ -19,7 +19,9 @@
 //
 // Bound: HBM once N is large (algorithmic bytes/source = F*8 source + 80 state r/w + 128 params + 8 peak);
 // at N = 256 it is latency-bound on the F-step recurrence (8 waves on a 256-CU part) -- DESIGN.md.
-#include "gas_internal.h"
+#include <cstdlib>
+
+#include "gas_biquad.h"
 
 // No FMA contraction in this file.  The recurrence is f32 with poles that approach the unit circle at low cutoffs /
 // small shelf gains (|p| up to 0.999x); there a fused multiply-add in place of the reference's separately rounded
@@ -42,41 +44,6 @@ constexpr int PARTS = COLS / 4; // 16-byte pieces per source row per tile
 constexpr int LOADS = SRC_PER_WG * PARTS / 64; // staging loads per lane per tile
 constexpr int GROUPS = 64 / COLS; // lane groups of the role-switch sum (2 at KF = 16, 1 at KF = 32)
 static_assert(KF == 16 || KF == 32, "tile size");
-
-struct Coeffs {
-	float b0, b1, b2, a1, a2;
-};
-
-// [ENGINE] AudioFilterSW::prepare_coefficients, HIGHSHELF, resonance 1, stages 1:
-// f64 arithmetic, members stored f32 before the division by a0, feedback terms negated.
-__device__ inline Coeffs highshelf_coeffs(float sampling_rate, float cutoff_hz, float gain_lin) {
-	int sr_limit = (int)(sampling_rate / 2) + 512;
-	double final_cutoff = ((double)cutoff_hz > sr_limit) ? (double)sr_limit : (double)cutoff_hz;
-	if (final_cutoff < 1) {
-		final_cutoff = 1;
-	}
-	double omega = 6.2831853071795864769252867666 * final_cutoff / (double)sampling_rate;
-	double sin_v = sin(omega);
-	double cos_v = cos(omega);
-	double A = gain_lin;
-	if (A < 0.001) {
-		A = 0.001;
-	}
-	double beta = sqrt(A); // sqrt(Q) = 1
-	double a0 = (A + 1.0) - (A - 1.0) * cos_v + beta * sin_v;
-	Coeffs c;
-	c.b0 = (float)(A * ((A + 1.0) + (A - 1.0) * cos_v + beta * sin_v));
-	c.b1 = (float)(-2.0 * A * ((A - 1.0) + (A + 1.0) * cos_v));
-	c.b2 = (float)(A * ((A + 1.0) + (A - 1.0) * cos_v - beta * sin_v));
-	c.a1 = (float)(2.0 * ((A - 1.0) - (A + 1.0) * cos_v));
-	c.a2 = (float)((A + 1.0) - (A - 1.0) * cos_v - beta * sin_v);
-	c.b0 = (float)((double)c.b0 / a0);
-	c.b1 = (float)((double)c.b1 / a0);
-	c.b2 = (float)((double)c.b2 / a0);
-	c.a1 = (float)((double)c.a1 / (0.0 - a0));
-	c.a2 = (float)((double)c.a2 / (0.0 - a0));
-	return c;
-}
 
 // Per-lane recurrence state.
 struct LaneState {
@@ -378,12 +345,24 @@ uint32_t gas_biquad_partials(uint32_t n) {
 	return (n + SRC_PER_WG - 1) / SRC_PER_WG;
 }
 
+// Few workgroups (no more than CUs): the launch is bound by one lane's dependent chain, not by memory -> the
+// eight-wave software pipeline of k_biquad_pipe.hip (bitwise the same results).  GAS_BIQUAD_PIPE=0 keeps the
+// single-wave kernel (development A/B; read per launch so that a test can switch inside one process).
+bool gas_biquad_uses_pipe(int mode, uint32_t n, uint32_t channel_count, uint32_t frames, bool rows_out) {
+	const char *pipe_env = std::getenv("GAS_BIQUAD_PIPE");
+	const bool pipe_on = !(pipe_env && pipe_env[0] == '0');
+	return pipe_on && !rows_out && mode != GAS_MODE_COPY && gas_biquad_partials(n) * channel_count <= 256 && frames % 32 == 0;
+}
+
 hipError_t gas_launch_biquad_mix(hipStream_t stream, int mode, const gas_group_args &g, const gas_dev_state &st, uint32_t frames, uint32_t channel_begin, uint32_t channel_count, float mix_rate, float *partials, uint32_t p_offset, uint32_t p_stride, float *rows_out) {
 	if (g.n == 0) {
 		return hipSuccess;
 	}
 	dim3 grid(gas_biquad_partials(g.n), channel_count);
 	dim3 block(64);
+	if (gas_biquad_uses_pipe(mode, g.n, channel_count, frames, rows_out != nullptr)) {
+		return gas_launch_biquad_pipe(stream, mode, g, st, frames, channel_begin, channel_count, mix_rate, partials, p_offset, p_stride);
+	}
 	switch (mode) {
 		case GAS_MODE_MIX_CHANNEL:
 			hipLaunchKernelGGL(k_biquad_mix<GAS_MODE_MIX_CHANNEL>, grid, block, 0, stream, g, st, frames, channel_begin, mix_rate, partials, p_offset, p_stride, rows_out);

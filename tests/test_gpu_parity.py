@@ -245,3 +245,41 @@ def test_hrtf_direction_runs_in_the_callers_list(gas, ob, chain, frames, ring):
         assert rel_rms(mix[0], r64[0]) <= TOL, f"block {b}"
         np.testing.assert_allclose(peaks[100], rpeaks[100], rtol=2e-5, atol=1e-7)
     ctx.close()
+
+
+@pytest.mark.parametrize("kind_name", ["mix_channel", "process_frames", "fx_highshelf"])
+@pytest.mark.parametrize("n,frames,channels", [(256, 512, 1), (37, 384, 2), (1000, 256, 1)])
+def test_biquad_pipeline_is_bitwise_the_single_wave_kernel(gas, kind_name, n, frames, channels):
+    """k_biquad_pipe (eight-wave software pipeline, small callbacks) against k_biquad_mix (one wave per 32 sources):
+    same operations, same rounding points -> the mixes, the peaks and the carried state (three callbacks, parameters
+    changing, some sources on the bypass branch) must agree to the bit.  GAS_BIQUAD_PIPE=0 selects the old kernel."""
+    import os
+
+    from godot_audio_spatializer_amd import synth
+
+    K = gas.capi
+    kind, chain = {"mix_channel": (K.KIND_3D_MIX, ()), "process_frames": (K.KIND_3D_PROCESS, ()), "fx_highshelf": (K.KIND_EFFECT, (K.FX_HIGHSHELF,))}[kind_name]
+    C = channels if kind == K.KIND_3D_MIX else 1
+
+    def render(pipe):
+        os.environ["GAS_BIQUAD_PIPE"] = "1" if pipe else "0"
+        rng = np.random.default_rng(11)
+        outs = []
+        with gas.SpatializerContext(max_sources=n, frames=frames, channel_count=channels) as ctx:
+            slots = ctx.source_alloc_many(n, kind, chain)
+            for cb in range(3):
+                p = synth.draw_params(rng, n, channel_count=channels, frames=frames)
+                p["linear_attenuation"][::5] = 0.0005  # bypass branch (:599-605) for every fifth source
+                ctx.params_publish_batch(slots, p)
+                mix, peaks = ctx.process_block(synth.draw_sources(rng, n, frames), slots)
+                outs.append((mix[:C].copy(), peaks.copy()))
+        return outs
+
+    try:
+        a, b = render(True), render(False)
+    finally:
+        os.environ.pop("GAS_BIQUAD_PIPE", None)
+    for (ma, pa), (mb, pb) in zip(a, b):
+        assert np.isfinite(ma).all() and np.abs(ma).max() > 0
+        np.testing.assert_array_equal(ma, mb)
+        np.testing.assert_array_equal(pa, pb)
