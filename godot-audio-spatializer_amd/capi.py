@@ -512,6 +512,10 @@ class MultiContext:
         L.gas_multi_note_alloc.argtypes = [vp, u32, i32]
         L.gas_multi_note_alloc.restype = None
         L.gas_multi_process_block.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(u32), u32, vp, C.POINTER(vp)]
+        L.gas_multi_process_block_mem.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(u32), u32, vp, C.POINTER(vp), i32]
+        L.gas_multi_synchronize.argtypes = [vp]
+        L.gas_multi_root_stream.argtypes = [vp]
+        L.gas_multi_root_stream.restype = vp
         self.frames, self.channel_count = frames, channel_count
         cfg = Config(C.sizeof(Config), 0, max_sources, frames, channel_count, mix_rate, er_ring_frames, flags)
         dev = (C.c_int32 * len(devices))(*devices)
@@ -534,6 +538,25 @@ class MultiContext:
                 s.h = None
             self.lib.gas_multi_destroy(self.h)
             self.h = None
+
+    def process_block_device(self, src_ptrs, slots_per_shard, out_ptr, peaks_ptrs=None):
+        """Device-memory callback: src_ptrs[g] / peaks_ptrs[g] are device addresses on shard g's device, out_ptr on the
+        root device; only enqueues (gas_multi_synchronize / the root stream order the result)."""
+        G = len(self.shards)
+        sls = [np.ascontiguousarray(s, dtype=np.uint32) for s in slots_per_shard]
+        vp = C.c_void_p
+        a_src = (vp * G)(*src_ptrs)
+        a_sl = (vp * G)(*[s.ctypes.data for s in sls])
+        a_pk = (vp * G)(*(peaks_ptrs if peaks_ptrs is not None else [None] * G))
+        a_n = (C.c_uint32 * G)(*[len(s) for s in sls])
+        rc = self.lib.gas_multi_process_block_mem(self.h, a_src, a_sl, a_n, self.frames, C.c_void_p(out_ptr), a_pk, MEM_DEVICE)
+        if rc != 0:
+            raise GasError(rc, "gas_multi_process_block_mem", self.lib.gas_strerror(rc).decode())
+
+    def synchronize(self):
+        rc = self.lib.gas_multi_synchronize(self.h)
+        if rc != 0:
+            raise GasError(rc, "gas_multi_synchronize", self.lib.gas_strerror(rc).decode())
 
     def process_block(self, src_per_shard, slots_per_shard):
         G = len(self.shards)

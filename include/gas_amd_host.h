@@ -76,8 +76,16 @@ gas_ctx *gas_multi_shard(gas_multi *m, uint32_t shard); /* the shard's context: 
 uint32_t gas_multi_least_loaded(gas_multi *m); /* shard with the fewest sources registered through gas_multi_note_alloc */
 void gas_multi_note_alloc(gas_multi *m, uint32_t shard, int delta); /* +1 after a gas_source_alloc on it, -1 after a free */
 /* One callback: src[g] is shard g's [n[g]][frames] host rows, slots[g] its slot list; out is the summed [C][frames] mix
- * (host); peaks[g] (may be NULL) receives shard g's [n[g]][2] peaks.  Host memory only. */
+ * (host); peaks[g] (may be NULL) receives shard g's [n[g]][2] peaks.  Host memory; = gas_multi_process_block_mem(.., GAS_MEM_HOST). */
 int gas_multi_process_block(gas_multi *m, const gas_audio_frame *const *src, const uint32_t *const *slots, const uint32_t *n, uint32_t frames, gas_audio_frame *out, float *const *peaks);
+/* The same with the memory kind spelled out.  GAS_MEM_DEVICE: src[g] / peaks[g] are device pointers on shard g's
+ * device, `out` a device pointer on the root device (devices[0]); the call only enqueues -- no allocation, no host
+ * wait -- and `out` is complete in the order of gas_multi_root_stream() / after gas_multi_synchronize().  GAS_MEM_HOST
+ * stages through per-shard buffers that only ever grow and ends in ONE wait on the root stream, which is
+ * event-chained behind every shard. */
+int gas_multi_process_block_mem(gas_multi *m, const gas_audio_frame *const *src, const uint32_t *const *slots, const uint32_t *n, uint32_t frames, gas_audio_frame *out, float *const *peaks, int mem);
+int gas_multi_synchronize(gas_multi *m);
+void *gas_multi_root_stream(gas_multi *m); /* hipStream_t of the root device on which `out` is produced */
 
 /* get_bus_map (audio_spatializer.cpp:274-324) for ONE bus: the per-channel-pair factors AudioServer multiplies the
  * frames returned for channel `channel` by.  Mix-channel instances mixed their volumes in already, so only the
