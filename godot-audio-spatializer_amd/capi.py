@@ -149,6 +149,7 @@ EXPORTS = [
     "gas_calc_spatialization_areas",
     "gas_stream_create",
     "gas_stream_destroy",
+    "gas_stream_set_resampled",
     "gas_source_bind_stream",
     "gas_process_block_streams",
     "gas_process_block",
@@ -217,6 +218,7 @@ def load_library():
     L.gas_hrtf_load.argtypes = [vp, vp, u32, u32]
     L.gas_stream_create.argtypes = [vp, vp, i32, u32, C.c_uint64, C.POINTER(u32)]
     L.gas_stream_destroy.argtypes = [vp, u32]
+    L.gas_stream_set_resampled.argtypes = [vp, u32, i32]
     L.gas_source_bind_stream.argtypes = [vp, u32, u32, C.c_uint64]
     L.gas_process_block_streams.argtypes = [vp, vp, u32, u32, vp, vp, vp, i32]
     L.gas_calc_spatialization.argtypes = [vp, vp, u32, vp, vp, vp, u32, vp, u32, vp, i32]
@@ -351,6 +353,9 @@ class SpatializerContext:
         sid = C.c_uint32()
         self._check(self.lib.gas_stream_create(self.h, _np_ptr(a), fmt, ch, a.shape[0], C.byref(sid)), "gas_stream_create")
         return sid.value
+
+    def stream_set_resampled(self, sid, on=True):
+        self._check(self.lib.gas_stream_set_resampled(self.h, sid, int(on)), "gas_stream_set_resampled")
 
     def stream_destroy(self, sid):
         self._check(self.lib.gas_stream_destroy(self.h, sid), "gas_stream_destroy")

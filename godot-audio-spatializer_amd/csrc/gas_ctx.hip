@@ -129,12 +129,15 @@ struct gas_ctx {
 		void *d_pcm = nullptr;
 		uint64_t frames = 0;
 		uint32_t format = 0, channels = 0;
+		bool resampled = false; // its playbacks are [ENGINE] AudioStreamPlaybackResampled (gas_stream_set_resampled)
 	};
 	std::vector<StreamInfo> streams;
 	gas_cursor *d_cursors = nullptr; // [max_sources]
 	std::vector<gas_cursor> h_cursors; // host mirror of the cursor arithmetic (deterministic, no read-back)
 	float *d_fade_env = nullptr; // [64]
 	uint32_t *d_stream_slots = nullptr; // callback slot list in row order
+	uint32_t *d_stream_inc = nullptr, *h_stream_inc = nullptr; // [max_sources] 16.16 step per row (resampled playbacks)
+	bool stream_any_resampled = false;
 	std::vector<uint32_t> stream_slots_host; // what d_stream_slots / the cached launch groups currently hold
 	// parameter rows published from device memory for the cached slot list (row order), not yet in the table
 	const gas_params *pending_params = nullptr;
@@ -144,6 +147,8 @@ struct gas_ctx {
 	struct StreamRow { // compact mirror of the cached list's cursors: the per-callback host loop touches only this
 		uint64_t remaining = 0;
 		uint32_t has_frames = 0, draining_marked = 0;
+		uint32_t resampled = 0, inc = 65536; // resampled playbacks: 16.16 step of this callback (from the host-published pitch_scale)
+		uint64_t fp_pos = 0, end_fp = 0; // ... and the engine's mix_offset / the stream's end, 16.16
 	};
 	std::vector<StreamRow> stream_rows;
 	bool stream_all_hrtf = false;
@@ -865,6 +870,8 @@ void gas_ctx_destroy(gas_ctx *c) {
 	(void)hipFree(c->d_cursors);
 	(void)hipFree(c->d_fade_env);
 	(void)hipFree(c->d_stream_slots);
+	(void)hipFree(c->d_stream_inc);
+	(void)hipHostFree(c->h_stream_inc);
 	for (auto &s : c->streams) {
 		(void)hipFree(s.d_pcm);
 	}
@@ -951,6 +958,8 @@ int gas_ctx_create(const gas_config *cfg, gas_ctx **out_ctx) {
 		GAS_HIP(c, hipMalloc(&c->d_cursors, sizeof(gas_cursor) * N));
 		GAS_HIP(c, hipMemsetAsync(c->d_cursors, 0, sizeof(gas_cursor) * N, c->stream));
 		GAS_HIP(c, hipMalloc(&c->d_stream_slots, sizeof(uint32_t) * N));
+		GAS_HIP(c, hipMalloc(&c->d_stream_inc, sizeof(uint32_t) * N));
+		GAS_HIP(c, hipHostMalloc(&c->h_stream_inc, sizeof(uint32_t) * N, hipHostMallocDefault));
 		{
 			// the reference's fade-out envelope, same f32 recurrence (audio_spatializer.cpp:382-392)
 			float env[GAS_LOOKAHEAD_BUFFER_SIZE];
@@ -1350,6 +1359,22 @@ int gas_stream_destroy(gas_ctx *c, uint32_t stream) {
 	return GAS_OK;
 }
 
+int gas_stream_set_resampled(gas_ctx *c, uint32_t stream, int on) {
+	if (!c) {
+		return GAS_ERR_INVALID_ARGUMENT;
+	}
+	if (stream >= c->streams.size() || !c->streams[stream].d_pcm) {
+		return GAS_ERR_BAD_SLOT;
+	}
+	for (const gas_cursor &cur : c->h_cursors) {
+		if (cur.pcm == c->streams[stream].d_pcm) {
+			return GAS_ERR_INVALID_ARGUMENT; // the playback class is chosen before playbacks are bound
+		}
+	}
+	c->streams[stream].resampled = on != 0;
+	return GAS_OK;
+}
+
 int gas_source_bind_stream(gas_ctx *c, uint32_t slot, uint32_t stream, uint64_t start_frame) {
 	if (!c) {
 		return GAS_ERR_INVALID_ARGUMENT;
@@ -1367,6 +1392,8 @@ int gas_source_bind_stream(gas_ctx *c, uint32_t slot, uint32_t stream, uint64_t 
 	cur.start = cur.pos;
 	cur.format_channels = (si.format << 8) | si.channels;
 	cur.has_frames = 1;
+	cur.resampled = si.resampled ? 1 : 0;
+	cur.fp_pos = cur.pos << 16; // [ENGINE] begin_resample: mix_offset = 0, zeroed interpolation history
 	c->h_cursors[slot] = cur;
 	GAS_HIP(c, hipSetDevice(c->cfg.device));
 	GAS_HIP(c, hipMemcpyAsync(c->d_cursors + slot, &c->h_cursors[slot], sizeof(gas_cursor), hipMemcpyHostToDevice, c->stream));
@@ -1388,6 +1415,9 @@ void stream_rows_sync_back(gas_ctx *c) {
 		const gas_ctx::StreamRow &r = c->stream_rows[i];
 		if (cur.pcm) {
 			cur.pos = cur.frames - r.remaining;
+		}
+		if (r.resampled) {
+			cur.fp_pos = r.fp_pos;
 		}
 		cur.has_frames = r.has_frames;
 	}
@@ -1423,8 +1453,13 @@ int gas_process_block_streams(gas_ctx *c, const uint32_t *slots, uint32_t n, uin
 			if (slots[i] >= c->cfg.max_sources || !c->slots[slots[i]].used) {
 				return fail(GAS_ERR_BAD_SLOT);
 			}
-			if (c->slots[slots[i]].has_params && c->h_params[slots[i]].pitch_scale != 1.0f && c->h_params[slots[i]].pitch_scale != 0.0f) {
-				return fail(GAS_ERR_UNSUPPORTED_CHAIN); // the device sampler does not resample (the host path does)
+			const float pitch = c->slots[slots[i]].has_params ? c->h_params[slots[i]].pitch_scale : 1.0f;
+			if (c->h_cursors[slots[i]].resampled) {
+				if (!(pitch >= 0.0f && pitch < 32768.0f)) {
+					return fail(GAS_ERR_INVALID_ARGUMENT);
+				}
+			} else if (pitch != 1.0f && pitch != 0.0f) {
+				return fail(GAS_ERR_UNSUPPORTED_CHAIN); // a non-resampled playback class (gas_stream_set_resampled is off)
 			}
 		}
 		// Everything gas_process_block could still reject is checked BEFORE a cursor moves: the reference consumes a
@@ -1452,11 +1487,34 @@ int gas_process_block_streams(gas_ctx *c, const uint32_t *slots, uint32_t n, uin
 		c->stream_slots_host.assign(slots, slots + n);
 		c->stream_rows.resize(n);
 		c->stream_all_hrtf = n > 0;
+		c->stream_any_resampled = false;
 		for (uint32_t i = 0; i < n; i++) {
 			const gas_cursor &cur = c->h_cursors[slots[i]];
-			c->stream_rows[i].remaining = cur.pcm && cur.frames > cur.pos ? cur.frames - cur.pos : 0;
-			c->stream_rows[i].has_frames = cur.pcm ? cur.has_frames : 0;
+			gas_ctx::StreamRow &r = c->stream_rows[i];
+			r.remaining = cur.pcm && cur.frames > cur.pos ? cur.frames - cur.pos : 0;
+			r.has_frames = cur.pcm ? cur.has_frames : 0;
+			r.resampled = cur.pcm ? cur.resampled : 0;
+			r.inc = 65536;
+			if (r.resampled) {
+				// [ENGINE] mix_increment = uint64((stream_rate * rate_scale / mix_rate) * FP_LEN), stream at the mix rate
+				const float pitch = c->slots[slots[i]].has_params ? c->h_params[slots[i]].pitch_scale : 1.0f;
+				r.inc = (uint32_t)(uint64_t)(((double)(c->cfg.mix_rate * pitch) / (double)c->cfg.mix_rate) * 65536.0);
+				r.fp_pos = cur.fp_pos;
+				r.end_fp = cur.frames << 16;
+				c->stream_any_resampled = true;
+			}
+			c->h_stream_inc[i] = r.inc;
 			c->stream_all_hrtf = c->stream_all_hrtf && c->slots[slots[i]].group == G_FX_HRTF;
+		}
+		if (c->stream_any_resampled) {
+			hipError_t e = hipMemcpyAsync(c->d_stream_inc, c->h_stream_inc, (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream);
+			if (e == hipSuccess) {
+				e = hipStreamSynchronize(c->stream); // the pinned staging array is rewritten by the next list
+			}
+			if (e != hipSuccess) {
+				c->last_err = hipGetErrorString(e);
+				return fail(GAS_ERR_DEVICE);
+			}
 		}
 		if (n > 0) {
 			hipError_t e = hipMemcpyAsync(c->d_stream_slots, c->stream_slots_host.data(), (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream);
@@ -1470,7 +1528,19 @@ int gas_process_block_streams(gas_ctx *c, const uint32_t *slots, uint32_t n, uin
 	bool draining_changed = false;
 	for (uint32_t i = 0; i < n; i++) {
 		gas_ctx::StreamRow &r = c->stream_rows[i];
-		if (r.has_frames) {
+		if (r.has_frames && r.resampled) { // same arithmetic as k_sample_sources' resampled branch
+			uint64_t mixed = F;
+			if (r.fp_pos >= r.end_fp) {
+				mixed = 0;
+			} else if (r.inc > 0) {
+				const uint64_t need = (r.end_fp - r.fp_pos + r.inc - 1) / r.inc;
+				mixed = need < F ? need : F;
+			}
+			r.fp_pos += (uint64_t)F * r.inc;
+			if (mixed != F) {
+				r.has_frames = 0;
+			}
+		} else if (r.has_frames) {
 			const uint32_t mixed = r.remaining < F ? (uint32_t)r.remaining : F;
 			r.remaining -= mixed;
 			if (mixed != F) {
@@ -1494,7 +1564,7 @@ int gas_process_block_streams(gas_ctx *c, const uint32_t *slots, uint32_t n, uin
 	}
 	// rows for this callback live in the library's staging buffer (not needed when k_hrtf_ols samples the
 	// streams itself: every playback a plain [HRTF] chain)
-	const bool all_hrtf = c->stream_all_hrtf;
+	const bool all_hrtf = c->stream_all_hrtf && !c->stream_any_resampled; // the fused prologue samples plain playbacks only
 	if (!all_hrtf) {
 		const size_t need = (size_t)n * F;
 		if (need > c->d_src_frames) {
@@ -1510,7 +1580,7 @@ int gas_process_block_streams(gas_ctx *c, const uint32_t *slots, uint32_t n, uin
 			c->d_src_frames = need;
 		}
 		if (n > 0) {
-			hipError_t e = gas_launch_sample_sources(c->stream, c->d_cursors, c->d_stream_slots, n, F, c->d_fade_env, c->d_src);
+			hipError_t e = gas_launch_sample_sources(c->stream, c->d_cursors, c->d_stream_slots, n, F, c->d_fade_env, c->d_src, c->stream_any_resampled ? c->d_stream_inc : nullptr);
 			if (e != hipSuccess) {
 				c->last_err = hipGetErrorString(e);
 				return fail(GAS_ERR_DEVICE);

@@ -42,6 +42,12 @@ struct gas_cursor {
 	uint64_t start; // first frame of this playback: the lookahead in front of it is zero (audio_spatializer.cpp:61-63)
 	uint32_t format_channels; // format << 8 | channels
 	uint32_t has_frames; // audio_spatializer.h:63
+	// resampled playbacks ([ENGINE] AudioStreamPlaybackResampled): the engine's mix_offset, 16.16 fixed point, in frames
+	// of the stream; and where / how fast the previous callback ran, from which its last 64 outputs (this callback's
+	// lookahead, audio_spatializer.cpp:369-373) are regenerated instead of being stored
+	uint64_t fp_pos, fp_prev_pos;
+	uint32_t prev_inc;
+	uint32_t resampled; // 0 plain, 1 resampled and never mixed yet (zeroed lookahead, :61-63), 2 resampled
 };
 
 // What a launch group (one kind/chain) needs.
@@ -109,7 +115,7 @@ void gas_make_twiddles(float2 *host_tw /* [64][16] */);
 hipError_t gas_launch_mix_reduce(hipStream_t stream, const float *partials, uint32_t p_count, uint32_t p_stride, uint32_t channels, uint32_t frames, gas_audio_frame *out);
 hipError_t gas_launch_scatter_params(hipStream_t stream, gas_params *table, const gas_params *upload, const uint32_t *slots, uint32_t n);
 hipError_t gas_launch_calc_spatialization(hipStream_t stream, const gas_spatializer3d_config *cfgs, const uint32_t *cfg_index, const gas_source_pose *poses, const gas_listener *listeners, uint32_t n_listeners, const uint32_t *slots, uint32_t n, gas_params *table, uint8_t *was_further, gas_params *out_params, const gas_area_send *areas = nullptr, const float *listener_area_pos = nullptr, gas_audio_frame *out_reverb = nullptr);
-hipError_t gas_launch_sample_sources(hipStream_t stream, gas_cursor *cursors, const uint32_t *slots, uint32_t n, uint32_t frames, const float *fade_env, gas_audio_frame *rows);
+hipError_t gas_launch_sample_sources(hipStream_t stream, gas_cursor *cursors, const uint32_t *slots, uint32_t n, uint32_t frames, const float *fade_env, gas_audio_frame *rows, const uint32_t *row_inc /* 16.16 step per row for resampled playbacks, or nullptr */);
 hipError_t gas_launch_noop(hipStream_t stream); // event-timer calibration
 hipError_t gas_launch_stream_probe(hipStream_t stream, const void *rd, uint64_t rd_bytes, void *wr, uint64_t wr_bytes, uint32_t workgroups, uint32_t unroll, float *sink); // copy-bandwidth ceiling
 #define GAS_DIR_ORDER_SEGMENT 8192

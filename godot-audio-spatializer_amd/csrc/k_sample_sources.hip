@@ -32,7 +32,30 @@ __device__ __forceinline__ gas_audio_frame load_frame(const void *pcm, uint32_t 
 	return gas_audio_frame{ s.x, s.y };
 }
 
-__global__ __launch_bounds__(256) void k_sample_sources(gas_cursor *__restrict__ cursors, const uint32_t *__restrict__ slots, uint32_t n, uint32_t F, const float *__restrict__ fade_env, gas_audio_frame *__restrict__ rows) {
+// [ENGINE] AudioStreamPlaybackResampled::mix, one output frame at 16.16 position `off` (oracle: stream_mix_resampled):
+// frames outside [start, len) read as zero.
+#pragma clang fp contract(off)
+__device__ __forceinline__ gas_audio_frame cubic_frame(const gas_cursor &c, uint32_t fmt, uint32_t ch, uint64_t off) {
+	const int64_t q = (int64_t)(off >> 16);
+	const float mu = (float)(uint32_t)(off & 0xFFFFu) / 65536.0f;
+	gas_audio_frame y[4];
+#pragma unroll
+	for (int k = 0; k < 4; k++) {
+		const int64_t j = q - 3 + k;
+		y[k] = (j >= (int64_t)c.start && j < (int64_t)c.frames) ? load_frame(c.pcm, fmt, ch, (uint64_t)j) : gas_audio_frame{ 0.0f, 0.0f };
+	}
+	const float mu2 = mu * mu;
+	const float h11 = mu2 * (mu - 1);
+	const float z = mu2 - h11;
+	const float h01 = z - h11;
+	const float h10 = mu - z;
+	gas_audio_frame o;
+	o.left = y[1].left + (y[2].left - y[1].left) * h01 + ((y[2].left - y[0].left) * h10 + (y[3].left - y[1].left) * h11) * 0.5f;
+	o.right = y[1].right + (y[2].right - y[1].right) * h01 + ((y[2].right - y[0].right) * h10 + (y[3].right - y[1].right) * h11) * 0.5f;
+	return o;
+}
+
+__global__ __launch_bounds__(256) void k_sample_sources(gas_cursor *__restrict__ cursors, const uint32_t *__restrict__ slots, uint32_t n, uint32_t F, const float *__restrict__ fade_env, gas_audio_frame *__restrict__ rows, const uint32_t *__restrict__ row_inc) {
 	const int lane = threadIdx.x & 63;
 	const uint32_t e = blockIdx.x * 4 + (threadIdx.x >> 6);
 	if (e >= n) {
@@ -42,6 +65,48 @@ __global__ __launch_bounds__(256) void k_sample_sources(gas_cursor *__restrict__
 	const gas_cursor c = *cp;
 	gas_audio_frame *row = rows + (size_t)e * F;
 	const uint32_t fmt = c.format_channels >> 8, ch = c.format_channels & 0xff;
+	if (c.resampled && c.has_frames && c.pcm) {
+		// The window the DSP sees is lookahead[64] ++ fresh[F] cut to F frames (audio_spatializer.cpp:367-378).  The fresh
+		// frames are this call's outputs at positions fp_pos + i * inc; the lookahead is the previous call's last 64
+		// outputs, regenerated from where and how fast that call ran.  The call reports as mixed the outputs produced
+		// before the position's integer part first reaches the end of the stream.
+		const uint64_t inc = row_inc ? row_inc[e] : 65536u;
+		const uint64_t end_fp = c.frames << 16;
+		uint64_t mixed64 = F;
+		if (c.fp_pos >= end_fp) {
+			mixed64 = 0;
+		} else if (inc > 0) {
+			const uint64_t need = (end_fp - c.fp_pos + inc - 1) / inc; // first i with fp_pos + i * inc >= end
+			mixed64 = need < F ? need : F;
+		}
+		const uint32_t mixed = (uint32_t)mixed64;
+		for (uint32_t i = lane; i < F; i += 64) {
+			gas_audio_frame v{ 0.0f, 0.0f };
+			if (mixed == F || i < mixed + GAS_LOOKAHEAD_BUFFER_SIZE) { // valid frames end at 64 + mixed
+				if (i >= GAS_LOOKAHEAD_BUFFER_SIZE) {
+					v = cubic_frame(c, fmt, ch, c.fp_pos + (uint64_t)(i - GAS_LOOKAHEAD_BUFFER_SIZE) * inc);
+				} else if (c.resampled == 2) {
+					v = cubic_frame(c, fmt, ch, c.fp_prev_pos + (uint64_t)(F - GAS_LOOKAHEAD_BUFFER_SIZE + i) * c.prev_inc);
+				}
+				if (mixed != F && i >= mixed) { // :389-392
+					const float f = fade_env[i - mixed];
+					v.left *= f;
+					v.right *= f;
+				}
+			}
+			row[i] = v;
+		}
+		if (lane == 0) {
+			cp->fp_prev_pos = c.fp_pos;
+			cp->prev_inc = (uint32_t)inc;
+			cp->fp_pos = c.fp_pos + (uint64_t)F * inc; // the engine advances over all requested frames
+			cp->resampled = 2;
+			if (mixed != F) {
+				cp->has_frames = 0; // :398
+			}
+		}
+		return;
+	}
 	uint32_t mixed = 0;
 	if (c.has_frames && c.pcm) {
 		const uint64_t left = c.frames > c.pos ? c.frames - c.pos : 0;
@@ -78,10 +143,10 @@ __global__ __launch_bounds__(256) void k_sample_sources(gas_cursor *__restrict__
 
 } // namespace
 
-hipError_t gas_launch_sample_sources(hipStream_t stream, gas_cursor *cursors, const uint32_t *slots, uint32_t n, uint32_t frames, const float *fade_env, gas_audio_frame *rows) {
+hipError_t gas_launch_sample_sources(hipStream_t stream, gas_cursor *cursors, const uint32_t *slots, uint32_t n, uint32_t frames, const float *fade_env, gas_audio_frame *rows, const uint32_t *row_inc) {
 	if (n == 0) {
 		return hipSuccess;
 	}
-	hipLaunchKernelGGL(k_sample_sources, dim3((n + 3) / 4), dim3(256), 0, stream, cursors, slots, n, frames, fade_env, rows);
+	hipLaunchKernelGGL(k_sample_sources, dim3((n + 3) / 4), dim3(256), 0, stream, cursors, slots, n, frames, fade_env, rows, row_inc);
 	return hipGetLastError();
 }

@@ -276,14 +276,23 @@ int gas_calc_spatialization_areas(gas_ctx *ctx, const gas_spatializer3d_config *
  * end-of-stream fade-out (audio_spatializer.cpp:367-408), over PCM that already lives in HBM, so a callback
  * moves no source frames over PCIe.  Streams are 16-bit PCM as in the reference's example asset
  * (speech_orig.wav: mono, 16-bit, 48 kHz); samples convert as s / 32768, mono feeds both ears [ENGINE].
- * Only pitch_scale == 1 at the context's mix rate is sampled on the device this round (no resampler);
- * anything else stays on the host path (gas_process_block with GAS_MEM_HOST). */
+ * Streams are taken to be at the context's mix rate; pitch-scaled playback: gas_stream_set_resampled. */
 typedef enum gas_pcm_format {
 	GAS_PCM_S16 = 0, /* interleaved little-endian int16 */
 	GAS_PCM_F32 = 1, /* interleaved float32 (already decoded) */
 } gas_pcm_format;
 
 int gas_stream_create(gas_ctx *ctx, const void *pcm, int format, uint32_t channels /* 1 or 2 */, uint64_t frames, uint32_t *out_stream);
+/* Which engine playback class stands behind the stream's playbacks (choose before binding them):
+ *   off (default): frames are handed out as they are; pitch_scale must be 1 (or 0 = unset), anything else is
+ *                  GAS_ERR_UNSUPPORTED_CHAIN;
+ *   on:            [ENGINE] AudioStreamPlaybackResampled::mix (audio_spatializer.cpp:375-378 passes pitch_scale per
+ *                  playback and callback; audio_spatializer_3d.cpp:405-434 sets it from doppler): a 16.16 fixed-point
+ *                  position advanced by pitch_scale per output frame and 4-point cubic interpolation over the frames
+ *                  q-3 .. q, at ANY pitch including 1 (where it is a 2-frame delay).  Recollection of the engine source,
+ *                  parity unpinned; the stream is taken to be at the context's mix rate.  pitch_scale is the value last
+ *                  published from the host (gas_params_publish*); 0 <= pitch_scale < 32768. */
+int gas_stream_set_resampled(gas_ctx *ctx, uint32_t stream, int on);
 int gas_stream_destroy(gas_ctx *ctx, uint32_t stream);
 /* start_playback_stream (audio_spatializer.cpp:55-63): the slot's playback starts at start_frame of the stream
  * with a zeroed lookahead and has_frames set. */

@@ -115,6 +115,9 @@ class Playback(C.Structure):
         ("pd3d", PData3D),
         ("pdfx", PDataEffect),
         ("last_peak", C.c_float * 2),
+        ("resampled", C.c_int32),
+        ("pad_", C.c_int32),
+        ("mix_offset", C.c_uint64),
     ]
 
 
@@ -202,7 +205,7 @@ def lib():
     L.gaso_fx_process.argtypes = [C.c_int, C.POINTER(Params), C.POINTER(FxState), C.POINTER(Hrtf), C.c_void_p, C.c_void_p, C.c_int, C.c_float]
     L.gaso_process_frames_effect.restype = C.c_uint32
     L.gaso_process_frames_effect.argtypes = [C.POINTER(Params), C.POINTER(PDataEffect), C.POINTER(Hrtf), C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_float]
-    L.gaso_fetch_source.argtypes = [C.POINTER(Playback), C.c_void_p, C.c_int]
+    L.gaso_fetch_source.argtypes = [C.POINTER(Playback), C.c_void_p, C.c_int, C.c_float, C.c_float]
     L.gaso_mix_from_playback_list.argtypes = [C.POINTER(Instance), C.POINTER(C.POINTER(Params)), C.POINTER(C.POINTER(Playback)), C.c_int, C.c_int]
     L.gaso_check_channel_mixed.restype = C.c_int
     L.gaso_check_channel_mixed.argtypes = [C.POINTER(Instance), C.c_int]

@@ -422,13 +422,46 @@ static int stream_mix(gaso_playback *pb, gaso_frame *dst, int n) {
 	return m;
 }
 
+/* [ENGINE] AudioStreamPlaybackResampled::mix (recollection of godotengine/godot servers/audio/audio_stream.cpp,
+ * unpinned): mix_increment = uint64((stream_rate * rate_scale / mix_rate) * 65536) with the stream at the mix rate;
+ * per output frame  mu = frac / 65536,  y0..y3 = frames q-3 .. q  (zero outside the stream),
+ *   mu2 = mu*mu; h11 = mu2*(mu-1); z = mu2-h11; h01 = z-h11; h10 = mu-z;
+ *   out = y1 + (y2-y1)*h01 + ((y2-y0)*h10 + (y3-y1)*h11)*0.5          (AudioFrame operators, f32)
+ * and the call reports as mixed the frames produced before q first reaches the stream's end. */
+static gaso_frame stream_at(const gaso_playback *pb, int64_t j) {
+	gaso_frame z = { 0.0f, 0.0f };
+	return (j >= 0 && j < pb->stream_frames) ? pb->stream[j] : z;
+}
+
+static int stream_mix_resampled(gaso_playback *pb, gaso_frame *dst, int n, float rate_scale, float mix_rate) {
+	const uint64_t inc = (uint64_t)(((double)(mix_rate * rate_scale) / (double)mix_rate) * 65536.0);
+	int mixed = -1;
+	for (int i = 0; i < n; i++) {
+		const int64_t q = (int64_t)(pb->mix_offset >> 16);
+		const float mu = (float)(pb->mix_offset & 0xFFFFu) / 65536.0f;
+		const gaso_frame y0 = stream_at(pb, q - 3), y1 = stream_at(pb, q - 2), y2 = stream_at(pb, q - 1), y3 = stream_at(pb, q);
+		if (q >= pb->stream_frames && mixed == -1) {
+			mixed = i;
+		}
+		const float mu2 = mu * mu;
+		const float h11 = mu2 * (mu - 1);
+		const float z = mu2 - h11;
+		const float h01 = z - h11;
+		const float h10 = mu - z;
+		dst[i].l = y1.l + (y2.l - y1.l) * h01 + ((y2.l - y0.l) * h10 + (y3.l - y1.l) * h11) * 0.5f;
+		dst[i].r = y1.r + (y2.r - y1.r) * h01 + ((y2.r - y0.r) * h10 + (y3.r - y1.r) * h11) * 0.5f;
+		pb->mix_offset += inc;
+	}
+	return mixed == -1 ? n : mixed;
+}
+
 /* audio_spatializer.cpp:367-408 */
-void gaso_fetch_source(gaso_playback *pb, gaso_frame *buf, int n) {
+void gaso_fetch_source(gaso_playback *pb, gaso_frame *buf, int n, float pitch_scale, float mix_rate) {
 	if (pb->has_frames) {
 		for (int i = 0; i < GASO_LOOKAHEAD; i++) { /* :371-373 */
 			buf[i] = pb->lookahead[i];
 		}
-		int mixed_frames = stream_mix(pb, &buf[GASO_LOOKAHEAD], n); /* :378 */
+		int mixed_frames = pb->resampled ? stream_mix_resampled(pb, &buf[GASO_LOOKAHEAD], n, pitch_scale, mix_rate) : stream_mix(pb, &buf[GASO_LOOKAHEAD], n); /* :375-378 */
 		if (mixed_frames != n) { /* :380-398 */
 			float fadeout_base = 0.96;
 			float fadeout_coefficient = 1;
@@ -533,7 +566,7 @@ void gaso_mix_from_playback_list(gaso_instance *inst, const gaso_params *const *
 			continue;
 		}
 		gaso_frame *buf = inst->playback_buffer;
-		gaso_fetch_source(pb, buf, n);
+		gaso_fetch_source(pb, buf, n, params[p]->pitch_scale, inst->mix_rate); /* :375 pitch_scale read per playback */
 		float peak[2];
 		gaso_playback_contribution(inst, params[p], &pb->pd3d, &pb->pdfx, buf, n, contrib, peak);
 		int channels = kind_should_mix_channels(inst->kind) ? inst->channel_count : 1;

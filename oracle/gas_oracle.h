@@ -143,8 +143,11 @@ enum {
 };
 
 /* audio_spatializer.h:55-66 SpatialPlaybackListNode with a synthetic stream
- * standing in for [ENGINE] AudioStreamPlayback::mix (pitch ignored: the
- * sampler is outside the path). */
+ * standing in for [ENGINE] AudioStreamPlayback::mix.  resampled == 0: a playback class
+ * that hands its frames out as they are (rate_scale ignored); resampled != 0:
+ * [ENGINE] AudioStreamPlaybackResampled::mix -- 16.16 fixed-point position advanced by
+ * rate_scale per output frame, 4-point cubic (Hermite) interpolation over the frames
+ * q-3 .. q (recollection of the engine source, parity unpinned). */
 typedef struct gaso_playback {
 	const gaso_frame *stream; /* stream_frames frames */
 	int64_t stream_frames;
@@ -155,6 +158,9 @@ typedef struct gaso_playback {
 	gaso_pdata3d pd3d;
 	gaso_pdata_effect pdfx;
 	float last_peak[2];
+	int32_t resampled;
+	int32_t pad_;
+	uint64_t mix_offset; /* resampled: position in the stream, 16.16 fixed point */
 } gaso_playback;
 
 typedef struct gaso_instance {
@@ -172,7 +178,7 @@ typedef struct gaso_instance {
 } gaso_instance;
 
 /* Source window + fade-out (audio_spatializer.cpp:367-408). Fills buf[0..n+64). */
-void gaso_fetch_source(gaso_playback *pb, gaso_frame *buf, int n);
+void gaso_fetch_source(gaso_playback *pb, gaso_frame *buf, int n, float pitch_scale, float mix_rate);
 /* Per-playback DSP, dispatch as audio_spatializer.cpp:410-462 but WITHOUT the
  * accumulate: writes the playback's contribution for channel c into
  * contrib[c][0..n) and returns its peak. Used by batched-vs-serial tests. */

@@ -169,3 +169,71 @@ def test_failed_streams_callback_consumes_no_frames(gas, ob):
             rc, want = rig.get_mixed_frames(0)
             assert rc == 0 and mix_matches(got[0], want), f"callback {cb}"
             assert [bool(x) for x in hf] == [bool(p.has_frames) for p in rig.pbs]
+
+
+@pytest.mark.parametrize("pitch", [0.5, 0.97, 1.0, 1.06, 2.0])
+@pytest.mark.parametrize("kind_name", ["effect_copy", "hrtf"])
+def test_resampled_streams_match_oracle_mixer(gas, ob, kind_name, pitch):
+    """Pitch-scaled device sampling (audio_spatializer.cpp:375-378 hands pitch_scale to the sampler; doppler sets it,
+    audio_spatializer_3d.cpp:405-434): playbacks of a gas_stream_set_resampled stream follow the oracle's restatement
+    of [ENGINE] AudioStreamPlaybackResampled::mix (16.16 position, 4-point cubic; engine recollection, parity
+    unpinned) through the lookahead window, the end-of-stream fade-out and the silence gate.  One playback changes
+    its pitch every callback (a moving source)."""
+    from godot_audio_spatializer_amd import synth
+
+    K = gas.capi
+    rng = np.random.default_rng(13)
+    F = 512
+    speech = np.load(SPEECH)
+    pcms = [speech[:4000], (rng.uniform(-0.5, 0.5, (2600, 2)) * 32767).astype(np.int16), rng.uniform(-0.5, 0.5, 1500).astype(np.float32), speech[1000:1000 + 3333]]
+    floats = [to_float_stereo(p) if p.dtype == np.int16 else np.stack([p, p], axis=1) for p in pcms]
+    n = len(pcms)
+    hrir = synth.synthetic_hrir(np.random.default_rng(7), dirs=8) if kind_name == "hrtf" else None
+    chain, ochain = ((K.FX_HRTF,), (ob.FX_HRTF,)) if kind_name == "hrtf" else ((), ())
+    params = synth.draw_params(rng, n, dirs=8)
+    params["pitch_scale"] = pitch
+    with gas.SpatializerContext(max_sources=n, frames=F, flags=K.FLAG_PEAKS_DRAINING_ONLY) as ctx:
+        if hrir is not None:
+            ctx.hrtf_load(hrir)
+        slots = ctx.source_alloc_many(n, K.KIND_EFFECT, chain)
+        for s, p in zip(slots, pcms):
+            sid = ctx.stream_create(p)
+            ctx.stream_set_resampled(sid, True)
+            ctx.source_bind_stream(s, sid)
+        rig = Rig(ob, ob.KIND_EFFECT, floats, F, chain=ochain, hrir=hrir)
+        for i in range(n):
+            rig.pbs[i].resampled = 1
+        active = np.ones(n, bool)
+        ended = 0
+        for cb in range(40):
+            params["pitch_scale"][3] = pitch * (1.0 + 0.03 * np.sin(cb))  # a moving source: doppler changes every tick
+            ctx.params_publish_batch(slots, params)
+            rig.params[:] = params.astype(ob.PARAMS_DTYPE)
+            live = slots[active]
+            got, peaks, hf = ctx.process_block_streams(live)
+            rc, want = rig.get_mixed_frames(0)
+            assert rc == 0
+            assert mix_matches(got[0], want), f"callback {cb}"
+            idx = np.flatnonzero(active)
+            for j, i in enumerate(idx):
+                assert bool(rig.pbs[i].has_frames) == bool(hf[j]), (cb, i)
+                if not hf[j]:
+                    np.testing.assert_allclose(peaks[j], tuple(rig.pbs[i].last_peak), rtol=2e-5, atol=1e-7)
+                    if peaks[j].max() <= 1e-4:
+                        active[i] = False
+                        ended += 1
+            for i in range(n):
+                assert active[i] == bool(rig.pbs[i].active), (cb, i)
+            if not active.any():
+                break
+        assert ended == n  # every playback ran out, faded, rang out and was gated off
+
+
+def test_resampled_class_is_chosen_before_binding(gas):
+    K = gas.capi
+    with gas.SpatializerContext(max_sources=1, frames=512) as ctx:
+        sid = ctx.stream_create(np.zeros(2048, np.int16))
+        slot = ctx.source_alloc(K.KIND_EFFECT)
+        ctx.source_bind_stream(slot, sid)
+        with pytest.raises(gas.GasError):
+            ctx.stream_set_resampled(sid, True)  # already bound
