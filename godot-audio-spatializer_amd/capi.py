@@ -107,6 +107,8 @@ SPAT3D_CONFIG_DTYPE = np.dtype(
 )
 POSE_DTYPE = np.dtype([("position", np.float32, (3,)), ("volume_db", np.float32), ("velocity", np.float32, (3,)), ("max_db", np.float32), ("forward", np.float32, (3,)), ("pitch_scale", np.float32)])
 AREA_SEND_DTYPE = np.dtype([("using_reverb_bus", np.uint32), ("reverb_uniformity", np.float32), ("reverb_amount", np.float32), ("present", np.uint32)])
+BUS_ROUTE_DTYPE = np.dtype([("dry_bus", np.uint32), ("send_bus", np.uint32), ("send", np.float32, (MAX_CHANNELS, 2))])
+BUS_NONE = 0xFFFFFFFF
 LISTENER_DTYPE = np.dtype([("basis", np.float32, (3, 3)), ("origin", np.float32, (3,)), ("velocity", np.float32, (3,)), ("pad", np.float32)])
 assert SPAT3D_CONFIG_DTYPE.itemsize == 64 and POSE_DTYPE.itemsize == 48 and LISTENER_DTYPE.itemsize == 64
 
@@ -153,6 +155,8 @@ EXPORTS = [
     "gas_source_bind_stream",
     "gas_process_block_streams",
     "gas_process_block",
+    "gas_bus_routes_publish",
+    "gas_process_block_buses",
     "gas_process_frames_1",
     "gas_mix_channel_1",
     "gas_profile_enable",
@@ -224,6 +228,8 @@ def load_library():
     L.gas_calc_spatialization.argtypes = [vp, vp, u32, vp, vp, vp, u32, vp, u32, vp, i32]
     L.gas_calc_spatialization_areas.argtypes = [vp, vp, u32, vp, vp, vp, u32, vp, u32, vp, vp, vp, vp, i32]
     L.gas_process_block.argtypes = [vp, vp, vp, u32, u32, vp, vp, i32]
+    L.gas_bus_routes_publish.argtypes = [vp, vp, vp, u32]
+    L.gas_process_block_buses.argtypes = [vp, vp, vp, u32, u32, vp, u32, vp, i32]
     L.gas_process_frames_1.argtypes = [vp, u32, vp, vp, i32]
     L.gas_mix_channel_1.argtypes = [vp, u32, i32, vp, vp, i32]
     L.gas_profile_enable.argtypes = [vp, i32]
@@ -390,6 +396,23 @@ class SpatializerContext:
         frames = src.shape[1] if src.ndim == 3 else self.frames
         rc = self.lib.gas_process_block(self.h, _np_ptr(src) if n else None, _np_ptr(s) if n else None, n, frames, _np_ptr(out), _np_ptr(peaks), MEM_HOST)
         self._check(rc, "gas_process_block")
+        return out, peaks[:n]
+
+    def bus_routes_publish(self, slots, routes):
+        s = np.ascontiguousarray(slots, dtype=np.uint32)
+        r = np.ascontiguousarray(routes, dtype=BUS_ROUTE_DTYPE)
+        assert s.shape == r.shape
+        self._check(self.lib.gas_bus_routes_publish(self.h, _np_ptr(s), _np_ptr(r), len(s)), "gas_bus_routes_publish")
+
+    def process_block_buses(self, src, slots, n_buses):
+        """Host-memory callback over several buses: -> (mix [n_buses][C][F][2], peaks [n][2])."""
+        src = np.ascontiguousarray(src, dtype=np.float32)
+        n = src.shape[0] if src.ndim == 3 else 0
+        s = np.ascontiguousarray(slots, dtype=np.uint32)
+        out = np.full((n_buses, self.channel_count, self.frames, 2), np.nan, dtype=np.float32)
+        peaks = np.zeros((max(n, 1), 2), dtype=np.float32)
+        rc = self.lib.gas_process_block_buses(self.h, _np_ptr(src) if n else None, _np_ptr(s) if n else None, n, self.frames, _np_ptr(out), n_buses, _np_ptr(peaks), MEM_HOST)
+        self._check(rc, "gas_process_block_buses")
         return out, peaks[:n]
 
     def process_block_raw(self, src_ptr, slots, n, frames, out_ptr, peaks_ptr, mem):

@@ -165,6 +165,14 @@ struct gas_ctx {
 	float *d_calc_lap = nullptr;
 	gas_audio_frame *d_calc_reverb = nullptr;
 
+	// several output buses: slot-indexed routes, host mirror + device table, own partial planes
+	std::vector<gas_bus_route> h_routes; // guarded by params_mu
+	bool routes_dirty = false;
+	gas_bus_route *h_routes_pinned = nullptr, *d_routes = nullptr;
+	float *d_bus_partials = nullptr;
+	size_t bus_partial_floats = 0;
+	gas_audio_frame *d_bus_out = nullptr; // [GAS_MAX_BUSES][C][F] staging for host-memory calls
+
 	// gas_bandwidth_probe: read arena (larger than the Infinity Cache, swept in rotation) and write target
 	void *d_probe_rd = nullptr, *d_probe_wr = nullptr;
 	size_t probe_rd_bytes = 0, probe_wr_bytes = 0;
@@ -875,6 +883,10 @@ void gas_ctx_destroy(gas_ctx *c) {
 	for (auto &s : c->streams) {
 		(void)hipFree(s.d_pcm);
 	}
+	(void)hipFree(c->d_routes);
+	(void)hipFree(c->d_bus_partials);
+	(void)hipFree(c->d_bus_out);
+	(void)hipHostFree(c->h_routes_pinned);
 	(void)hipFree(c->d_probe_rd);
 	(void)hipFree(c->d_probe_wr);
 	(void)hipFree(c->d_probe_sink);
@@ -995,6 +1007,7 @@ int gas_ctx_create(const gas_config *cfg, gas_ctx **out_ctx) {
 		return rc;
 	}
 	c->slots.resize(N);
+	c->h_routes.assign(N, gas_bus_route{ 0, GAS_BUS_NONE, {} });
 	c->h_cursors.assign(N, gas_cursor{});
 	c->stamp.assign(N, 0);
 	c->dirty_flag.assign(N, 0);
@@ -1761,6 +1774,145 @@ int gas_process_block(gas_ctx *c, const gas_audio_frame *src, const uint32_t *sl
 	return GAS_OK;
 }
 
+int gas_bus_routes_publish(gas_ctx *c, const uint32_t *slots, const gas_bus_route *routes, uint32_t n) {
+	if (!c || (n > 0 && (!slots || !routes))) {
+		return GAS_ERR_INVALID_ARGUMENT;
+	}
+	for (uint32_t i = 0; i < n; i++) {
+		if (slots[i] >= c->cfg.max_sources || !c->slots[slots[i]].used) {
+			return GAS_ERR_BAD_SLOT;
+		}
+	}
+	std::lock_guard<std::mutex> lk(c->params_mu);
+	for (uint32_t i = 0; i < n; i++) {
+		c->h_routes[slots[i]] = routes[i];
+	}
+	c->routes_dirty = true;
+	return GAS_OK;
+}
+
+// AudioSpatializer3D's buses in one launch: the mix_channel kernel with per-source weights per bus, its partial
+// planes summed by the ordinary deterministic reduce (bus-major: plane b * C + c).
+int gas_process_block_buses(gas_ctx *c, const gas_audio_frame *src, const uint32_t *slots, uint32_t n, uint32_t frames, gas_audio_frame *out, uint32_t n_buses, float *peaks, int mem) {
+	if (!c || !out || (mem != GAS_MEM_HOST && mem != GAS_MEM_DEVICE) || (n > 0 && (!src || !slots)) || n > c->cfg.max_sources || n_buses < 1 || n_buses > GAS_MAX_BUSES) {
+		return GAS_ERR_INVALID_ARGUMENT;
+	}
+	const uint32_t F = c->cfg.frames, C = c->cfg.channel_count;
+	const size_t out_bytes = (size_t)n_buses * C * F * sizeof(gas_audio_frame);
+	auto fail = [&](int code) {
+		if (mem == GAS_MEM_HOST) {
+			std::memset(out, 0, out_bytes);
+		}
+		return code;
+	};
+	if (frames != F) {
+		return fail(GAS_ERR_FRAME_COUNT);
+	}
+	if (hipSetDevice(c->cfg.device) != hipSuccess) {
+		return fail(GAS_ERR_NO_DEVICE);
+	}
+	int rc = flush_pending_params(c);
+	if (rc != GAS_OK) {
+		return fail(rc);
+	}
+	apply_pending_frees(c);
+	rc = build_groups(c, slots, n);
+	if (rc != GAS_OK) {
+		c->cached_n = UINT32_MAX;
+		return fail(rc);
+	}
+	for (int gt = 0; gt < G_COUNT; gt++) {
+		if (gt != G_3D_MIX && c->groups[gt].count > 0) {
+			c->cached_n = UINT32_MAX;
+			return fail(GAS_ERR_UNSUPPORTED_CHAIN); // bus routing restates AudioSpatializer3D's mix-channel buses only
+		}
+	}
+	rc = join_outputs(c);
+	if (rc == GAS_OK) {
+		rc = flush_params(c);
+	}
+	if (rc != GAS_OK) {
+		return fail(rc);
+	}
+	rc = [&]() -> int {
+		// routes snapshot (latest wins), like the parameters
+		bool upload = false;
+		{
+			std::lock_guard<std::mutex> lk(c->params_mu);
+			if (c->routes_dirty || !c->d_routes) {
+				if (!c->h_routes_pinned) {
+					GAS_HIP(c, hipHostMalloc(&c->h_routes_pinned, sizeof(gas_bus_route) * c->cfg.max_sources, hipHostMallocDefault));
+					GAS_HIP(c, hipMalloc(&c->d_routes, sizeof(gas_bus_route) * c->cfg.max_sources));
+				}
+				std::memcpy(c->h_routes_pinned, c->h_routes.data(), sizeof(gas_bus_route) * c->cfg.max_sources);
+				c->routes_dirty = false;
+				upload = true;
+			}
+		}
+		if (upload) {
+			GAS_HIP(c, hipMemcpyAsync(c->d_routes, c->h_routes_pinned, sizeof(gas_bus_route) * c->cfg.max_sources, hipMemcpyHostToDevice, c->stream));
+			GAS_HIP(c, hipStreamSynchronize(c->stream)); // the pinned mirror is rewritten by the next snapshot
+		}
+		const uint32_t P = n ? gas_biquad_partials(n) : 0;
+		const size_t need = (size_t)n_buses * C * (P ? P : 1) * F * 2;
+		if (need > c->bus_partial_floats) {
+			GAS_HIP(c, hipStreamSynchronize(c->stream));
+			(void)hipFree(c->d_bus_partials);
+			c->d_bus_partials = nullptr;
+			c->bus_partial_floats = 0;
+			GAS_HIP(c, hipMalloc(&c->d_bus_partials, need * sizeof(float)));
+			c->bus_partial_floats = need;
+		}
+		const gas_audio_frame *d_src = src;
+		gas_audio_frame *d_out = out;
+		float *d_peaks = peaks ? peaks : c->d_peaks;
+		if (mem == GAS_MEM_HOST) {
+			const size_t rows = (size_t)n * F;
+			if (rows > c->d_src_frames) {
+				(void)hipFree(c->d_src);
+				c->d_src = nullptr;
+				c->d_src_frames = 0;
+				GAS_HIP(c, hipMalloc(&c->d_src, rows * sizeof(gas_audio_frame)));
+				c->d_src_frames = rows;
+			}
+			if (n > 0) {
+				GAS_HIP(c, hipMemcpyAsync(c->d_src, src, rows * sizeof(gas_audio_frame), hipMemcpyHostToDevice, c->stream));
+			}
+			if (!c->d_bus_out) {
+				GAS_HIP(c, hipMalloc(&c->d_bus_out, (size_t)GAS_MAX_BUSES * C * F * sizeof(gas_audio_frame)));
+			}
+			d_src = c->d_src;
+			d_out = c->d_bus_out;
+			d_peaks = c->d_peaks;
+		}
+		if (n > 0) {
+			GAS_HIP(c, hipMemsetAsync(d_peaks, 0, (size_t)n * 2 * sizeof(float), c->stream)); // k_biquad_mix accumulates peaks over channel pairs
+			gas_group_args ga;
+			ga.src = d_src;
+			ga.rows = c->cached_identity_rows ? nullptr : c->d_rows;
+			ga.slots = c->d_slots;
+			ga.slot_base = 0;
+			ga.n = n;
+			ga.peaks = d_peaks;
+			gas_bus_args ba;
+			ba.routes = c->d_routes;
+			ba.n_buses = n_buses;
+			// force the multi-bus code even for one bus when the caller routes (a lone bus other than 0 is legal)
+			GAS_HIP(c, gas_launch_biquad_mix(c->stream, GAS_MODE_MIX_CHANNEL, ga, c->st, F, 0, C, c->cfg.mix_rate, c->d_bus_partials, 0, P, nullptr, ba));
+		}
+		GAS_HIP(c, gas_launch_mix_reduce(c->stream, c->d_bus_partials, P, P ? P : 1, n_buses * C, F, d_out));
+		if (mem == GAS_MEM_HOST) {
+			GAS_HIP(c, hipMemcpyAsync(out, c->d_bus_out, out_bytes, hipMemcpyDeviceToHost, c->stream));
+			if (peaks && n > 0) {
+				GAS_HIP(c, hipMemcpyAsync(peaks, c->d_peaks, (size_t)n * 2 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+			}
+			GAS_HIP(c, hipStreamSynchronize(c->stream));
+		}
+		return GAS_OK;
+	}();
+	return rc == GAS_OK ? GAS_OK : fail(rc);
+}
+
 static int process_one(gas_ctx *c, uint32_t slot, int channel, bool mix_channel, gas_audio_frame *out, const gas_audio_frame *src, int frame_count) {
 	if (!c || !out || !src) {
 		return GAS_ERR_INVALID_ARGUMENT;
@@ -1891,7 +2043,11 @@ int gas_bandwidth_probe(gas_ctx *c, uint64_t read_bytes, uint64_t write_bytes, u
 	// the read arena is swept in rotation so that successive launches cannot be served by the 256 MiB Infinity Cache
 	const size_t want_rd = read_bytes ? ((size_t)(320u << 20) / read_bytes + 2) * read_bytes : 16;
 	if (want_rd > c->probe_rd_bytes) {
-		(void)hipFree(c->d_probe_rd);
+		(void)hipFree(c->d_routes);
+	(void)hipFree(c->d_bus_partials);
+	(void)hipFree(c->d_bus_out);
+	(void)hipHostFree(c->h_routes_pinned);
+	(void)hipFree(c->d_probe_rd);
 		c->d_probe_rd = nullptr;
 		c->probe_rd_bytes = 0;
 		GAS_HIP(c, hipMalloc(&c->d_probe_rd, want_rd));

@@ -83,16 +83,23 @@ struct gas_hrtf_table {
 	uint32_t dirs;
 };
 
+// Several output buses: per-slot routes and how many buses the launch writes.  n_buses <= 1 is the
+// single mix of gas_process_block (routes unused).  Partial layout with buses: plane (b * channel_count + c).
+struct gas_bus_args {
+	const gas_bus_route *routes = nullptr; // [max_sources], slot-indexed
+	uint32_t n_buses = 1;
+};
+
 // Launchers (each only enqueues on `stream`; geometry is validated by the caller).
 // Returns the number of partial mixes (per channel) it writes into `partials`
 // ([C][P][F*2] floats, row stride P_stride).
 uint32_t gas_biquad_partials(uint32_t n); // P for n sources
-hipError_t gas_launch_biquad_mix(hipStream_t stream, int mode, const gas_group_args &g, const gas_dev_state &st, uint32_t frames, uint32_t channel_begin, uint32_t channel_count, float mix_rate, float *partials, uint32_t p_offset, uint32_t p_stride, float *rows_out = nullptr /* non-null: per-source rows instead of the partial mix */);
+hipError_t gas_launch_biquad_mix(hipStream_t stream, int mode, const gas_group_args &g, const gas_dev_state &st, uint32_t frames, uint32_t channel_begin, uint32_t channel_count, float mix_rate, float *partials, uint32_t p_offset, uint32_t p_stride, float *rows_out = nullptr /* non-null: per-source rows instead of the partial mix */, const gas_bus_args &buses = gas_bus_args());
 
 // k_biquad_pipe.hip: the same arithmetic as an eight-wave software pipeline per 32 sources, for callbacks with fewer
 // workgroups than CUs (chosen inside gas_launch_biquad_mix)
 bool gas_biquad_uses_pipe(int mode, uint32_t n, uint32_t channel_count, uint32_t frames, bool rows_out); // the launcher's choice
-hipError_t gas_launch_biquad_pipe(hipStream_t stream, int mode, const gas_group_args &g, const gas_dev_state &st, uint32_t frames, uint32_t channel_begin, uint32_t channel_count, float mix_rate, float *partials, uint32_t p_offset, uint32_t p_stride);
+hipError_t gas_launch_biquad_pipe(hipStream_t stream, int mode, const gas_group_args &g, const gas_dev_state &st, uint32_t frames, uint32_t channel_begin, uint32_t channel_count, float mix_rate, float *partials, uint32_t p_offset, uint32_t p_stride, const gas_bus_args &buses = gas_bus_args());
 
 struct gas_hrtf_launch_plan {
 	uint32_t wgs_fd, wgs_pk; // workgroups = partial mixes written

@@ -57,7 +57,7 @@ struct LaneState {
 // The tile loop, specialised on the two wave-uniform conditions so neither the IEEE division of the
 // non-power-of-two lerp nor the bypass-branch selects are evaluated per step.
 template <int MODE, bool F_POW2, bool ALL_FILT>
-__device__ __forceinline__ void run_tiles(LaneState &L, float (&tile)[2][SRC_PER_WG * ROW], const float *const (&ld_base)[LOADS], uint32_t F, float *__restrict__ my_partial, int lane, int sl, int ear, const bool rows_mode, float *const (&st_base)[LOADS]) {
+__device__ __forceinline__ void run_tiles(LaneState &L, float (&tile)[2][SRC_PER_WG * ROW], const float *const (&ld_base)[LOADS], uint32_t F, float *__restrict__ my_partial, int lane, int sl, int ear, const bool rows_mode, float *const (&st_base)[LOADS], uint32_t n_buses = 1, const float *bus_w = nullptr, size_t bus_plane = 0) {
 	Coeffs co = L.co, inc = L.inc;
 	float ha1 = L.ha1, ha2 = L.ha2, hb1 = L.hb1, hb2 = L.hb2;
 	const float vs = L.vs, vf = L.vf;
@@ -175,8 +175,28 @@ __device__ __forceinline__ void run_tiles(LaneState &L, float (&tile)[2][SRC_PER
 				const float s_hi = __shfl_down(s, 32);
 				s += s_hi;
 			}
-			if (lane < COLS) {
-				my_partial[(size_t)tl * COLS + j] = s;
+			if (n_buses == 0) {
+				if (lane < COLS) {
+					my_partial[(size_t)tl * COLS + j] = s;
+				}
+			} else {
+				// several buses: the same column, weighted per source by what that source sends to the
+				// bus (dry 1, send = bus / mix volume; audio_spatializer.cpp:295-313), product then sum like AudioServer's
+				// per-bus multiply-accumulate
+				for (uint32_t b = 0; b < n_buses; b++) {
+					const float *w = bus_w + b * 64 + (PER * h) * 2 + (j & 1);
+					float sb = 0.0f;
+#pragma unroll
+					for (int k = 0; k < PER; k++) {
+						sb += col[k * ROW] * w[2 * k];
+					}
+					if constexpr (GROUPS == 2) {
+						sb += __shfl_down(sb, 32);
+					}
+					if (lane < COLS) {
+						my_partial[b * bus_plane + (size_t)tl * COLS + j] = sb;
+					}
+				}
 			}
 		}
 		}
@@ -193,8 +213,9 @@ __device__ __forceinline__ void run_tiles(LaneState &L, float (&tile)[2][SRC_PER
 }
 
 template <int MODE>
-__global__ __launch_bounds__(64) void k_biquad_mix(gas_group_args g, gas_dev_state st, uint32_t F, uint32_t c0, float mix_rate, float *__restrict__ partials, uint32_t p_offset, uint32_t p_stride, float *__restrict__ rows_out) {
+__global__ __launch_bounds__(64) void k_biquad_mix(gas_group_args g, gas_dev_state st, uint32_t F, uint32_t c0, float mix_rate, float *__restrict__ partials, uint32_t p_offset, uint32_t p_stride, float *__restrict__ rows_out, gas_bus_args buses) {
 	__shared__ float tile[2][SRC_PER_WG * ROW];
+	__shared__ float bus_w[GAS_MAX_BUSES * 64]; // [bus][source * 2 + ear]: what each source sends to each bus for this pair
 
 	const int lane = threadIdx.x;
 	const int ear = lane & 1;
@@ -294,18 +315,34 @@ __global__ __launch_bounds__(64) void k_biquad_mix(gas_group_args g, gas_dev_sta
 	const bool all_filt = __all(filt || !valid);
 	const bool f_pow2 = (F & (F - 1)) == 0;
 	float *my_partial = partials + ((size_t)blockIdx.y * p_stride + p_offset + blockIdx.x) * (size_t)F * 2;
+	const size_t bus_plane = (size_t)gridDim.y * p_stride * (size_t)F * 2; // floats between the partial planes of two buses
+	const uint32_t n_buses = buses.routes ? buses.n_buses : 0; // 0: the single mix of gas_process_block
+	if (n_buses > 0) {
+		gas_bus_route r{ 0, GAS_BUS_NONE, {} };
+		if (valid) {
+			r = buses.routes[slot];
+		}
+		for (uint32_t b = 0; b < n_buses; b++) {
+			float w = 0.0f;
+			if (valid) {
+				w = (r.dry_bus == b ? 1.0f : 0.0f) + (r.send_bus == b ? r.send[c][ear] : 0.0f);
+			}
+			bus_w[b * 64 + lane] = w;
+		}
+		__syncthreads();
+	}
 	LaneState L{ co, inc, ha1, ha2, hb1, hb2, vs, vf, 0.0f, filt, valid };
 	if (f_pow2) {
 		if (all_filt) {
-			run_tiles<MODE, true, true>(L, tile, ld_base, F, my_partial, lane, sl, ear, rows_out != nullptr, st_base);
+			run_tiles<MODE, true, true>(L, tile, ld_base, F, my_partial, lane, sl, ear, rows_out != nullptr, st_base, n_buses, bus_w, bus_plane);
 		} else {
-			run_tiles<MODE, true, false>(L, tile, ld_base, F, my_partial, lane, sl, ear, rows_out != nullptr, st_base);
+			run_tiles<MODE, true, false>(L, tile, ld_base, F, my_partial, lane, sl, ear, rows_out != nullptr, st_base, n_buses, bus_w, bus_plane);
 		}
 	} else {
 		if (all_filt) {
-			run_tiles<MODE, false, true>(L, tile, ld_base, F, my_partial, lane, sl, ear, rows_out != nullptr, st_base);
+			run_tiles<MODE, false, true>(L, tile, ld_base, F, my_partial, lane, sl, ear, rows_out != nullptr, st_base, n_buses, bus_w, bus_plane);
 		} else {
-			run_tiles<MODE, false, false>(L, tile, ld_base, F, my_partial, lane, sl, ear, rows_out != nullptr, st_base);
+			run_tiles<MODE, false, false>(L, tile, ld_base, F, my_partial, lane, sl, ear, rows_out != nullptr, st_base, n_buses, bus_w, bus_plane);
 		}
 	}
 	co = L.co;
@@ -354,27 +391,27 @@ bool gas_biquad_uses_pipe(int mode, uint32_t n, uint32_t channel_count, uint32_t
 	return pipe_on && !rows_out && mode != GAS_MODE_COPY && gas_biquad_partials(n) * channel_count <= 256 && frames % 32 == 0;
 }
 
-hipError_t gas_launch_biquad_mix(hipStream_t stream, int mode, const gas_group_args &g, const gas_dev_state &st, uint32_t frames, uint32_t channel_begin, uint32_t channel_count, float mix_rate, float *partials, uint32_t p_offset, uint32_t p_stride, float *rows_out) {
+hipError_t gas_launch_biquad_mix(hipStream_t stream, int mode, const gas_group_args &g, const gas_dev_state &st, uint32_t frames, uint32_t channel_begin, uint32_t channel_count, float mix_rate, float *partials, uint32_t p_offset, uint32_t p_stride, float *rows_out, const gas_bus_args &buses) {
 	if (g.n == 0) {
 		return hipSuccess;
 	}
 	dim3 grid(gas_biquad_partials(g.n), channel_count);
 	dim3 block(64);
 	if (gas_biquad_uses_pipe(mode, g.n, channel_count, frames, rows_out != nullptr)) {
-		return gas_launch_biquad_pipe(stream, mode, g, st, frames, channel_begin, channel_count, mix_rate, partials, p_offset, p_stride);
+		return gas_launch_biquad_pipe(stream, mode, g, st, frames, channel_begin, channel_count, mix_rate, partials, p_offset, p_stride, buses);
 	}
 	switch (mode) {
 		case GAS_MODE_MIX_CHANNEL:
-			hipLaunchKernelGGL(k_biquad_mix<GAS_MODE_MIX_CHANNEL>, grid, block, 0, stream, g, st, frames, channel_begin, mix_rate, partials, p_offset, p_stride, rows_out);
+			hipLaunchKernelGGL(k_biquad_mix<GAS_MODE_MIX_CHANNEL>, grid, block, 0, stream, g, st, frames, channel_begin, mix_rate, partials, p_offset, p_stride, rows_out, buses);
 			break;
 		case GAS_MODE_PROCESS_FRAMES:
-			hipLaunchKernelGGL(k_biquad_mix<GAS_MODE_PROCESS_FRAMES>, grid, block, 0, stream, g, st, frames, channel_begin, mix_rate, partials, p_offset, p_stride, rows_out);
+			hipLaunchKernelGGL(k_biquad_mix<GAS_MODE_PROCESS_FRAMES>, grid, block, 0, stream, g, st, frames, channel_begin, mix_rate, partials, p_offset, p_stride, rows_out, buses);
 			break;
 		case GAS_MODE_FX_HIGHSHELF:
-			hipLaunchKernelGGL(k_biquad_mix<GAS_MODE_FX_HIGHSHELF>, grid, block, 0, stream, g, st, frames, channel_begin, mix_rate, partials, p_offset, p_stride, rows_out);
+			hipLaunchKernelGGL(k_biquad_mix<GAS_MODE_FX_HIGHSHELF>, grid, block, 0, stream, g, st, frames, channel_begin, mix_rate, partials, p_offset, p_stride, rows_out, buses);
 			break;
 		case GAS_MODE_COPY:
-			hipLaunchKernelGGL(k_biquad_mix<GAS_MODE_COPY>, grid, block, 0, stream, g, st, frames, channel_begin, mix_rate, partials, p_offset, p_stride, rows_out);
+			hipLaunchKernelGGL(k_biquad_mix<GAS_MODE_COPY>, grid, block, 0, stream, g, st, frames, channel_begin, mix_rate, partials, p_offset, p_stride, rows_out, buses);
 			break;
 		default:
 			return hipErrorInvalidValue;

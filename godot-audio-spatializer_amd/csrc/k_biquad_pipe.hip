@@ -74,10 +74,11 @@ struct PipeLds {
 	float2 ux[2][KF * 64]; // (u, x) per step per lane: the general form (some lane takes the bypass branch)
 	float u1[2][KF * 64]; // u alone when every lane filters (half the store traffic of the hand-over)
 	float yo[2][KF * YROW]; // outputs per step per lane
+	float bus_w[GAS_MAX_BUSES * 64]; // several buses: [bus][source * 2 + ear] weights for this channel pair
 };
 
 template <int MODE, bool F_POW2, bool ALL_FILT>
-__global__ __launch_bounds__(N_WAVES * 64) void k_biquad_pipe(gas_group_args g, gas_dev_state st, uint32_t F, uint32_t c0, float mix_rate, float *__restrict__ partials, uint32_t p_offset, uint32_t p_stride) {
+__global__ __launch_bounds__(N_WAVES * 64) void k_biquad_pipe(gas_group_args g, gas_dev_state st, uint32_t F, uint32_t c0, float mix_rate, float *__restrict__ partials, uint32_t p_offset, uint32_t p_stride, gas_bus_args buses) {
 	__shared__ PipeLds L;
 	const int lane = threadIdx.x & 63;
 	const int role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -138,6 +139,17 @@ __global__ __launch_bounds__(N_WAVES * 64) void k_biquad_pipe(gas_group_args g, 
 	const float Ff = (float)Fi;
 	const float invF = 1.0f / Ff;
 	float *my_partial = partials + ((size_t)blockIdx.y * p_stride + p_offset + blockIdx.x) * (size_t)F * 2;
+	const size_t bus_plane = (size_t)gridDim.y * p_stride * (size_t)F * 2; // floats between the partial planes of two buses
+	const uint32_t n_buses = buses.routes ? buses.n_buses : 0; // 0: the single mix of gas_process_block
+	if (n_buses > 0 && role == R_POST) { // only POST reads the weights (its own writes)
+		gas_bus_route r{ 0, GAS_BUS_NONE, {} };
+		if (valid) {
+			r = buses.routes[slot];
+		}
+		for (uint32_t b = 0; b < n_buses; b++) {
+			L.bus_w[b * 64 + lane] = valid ? (r.dry_bus == b ? 1.0f : 0.0f) + (r.send_bus == b ? r.send[c][ear] : 0.0f) : 0.0f;
+		}
+	}
 
 	// ---- role state ------------------------------------------------------------------------------------------------------
 	float b0 = 0, b1 = 0, b2 = 0, ib0 = 0, ib1 = 0, ib2 = 0; // COEF
@@ -365,14 +377,26 @@ __global__ __launch_bounds__(N_WAVES * 64) void k_biquad_pipe(gas_group_args g, 
 				for (int k = 0; k < SRC_PER_WG; k++) {
 					cv[k] = col[2 * k];
 				}
-				float s = 0.0f;
+				if (n_buses == 0) {
+					float s = 0.0f;
 #pragma unroll
-				for (int k = 0; k < SRC_PER_WG; k++) {
-					if ((uint32_t)k < n_valid) { // wave-uniform
-						s += cv[k];
+					for (int k = 0; k < SRC_PER_WG; k++) {
+						if ((uint32_t)k < n_valid) { // wave-uniform
+							s += cv[k];
+						}
+					}
+					my_partial[(size_t)t * COLS + lane] = s;
+				} else { // per bus: product with what the source sends there, then the ordered sum (k_biquad_mix.hip)
+					for (uint32_t b = 0; b < n_buses; b++) {
+						const float *w = L.bus_w + b * 64 + ear;
+						float sb = 0.0f;
+#pragma unroll
+						for (int k = 0; k < SRC_PER_WG; k++) {
+							sb += cv[k] * w[2 * k];
+						}
+						my_partial[b * bus_plane + (size_t)t * COLS + lane] = sb;
 					}
 				}
-				my_partial[(size_t)t * COLS + lane] = s;
 			}
 		}
 #ifdef GAS_STAMPS
@@ -417,19 +441,19 @@ __global__ __launch_bounds__(N_WAVES * 64) void k_biquad_pipe(gas_group_args g, 
 }
 
 template <int MODE>
-void launch_pipe(hipStream_t stream, dim3 grid, bool f_pow2, bool all_filt, const gas_group_args &g, const gas_dev_state &st, uint32_t frames, uint32_t channel_begin, float mix_rate, float *partials, uint32_t p_offset, uint32_t p_stride) {
+void launch_pipe(hipStream_t stream, dim3 grid, bool f_pow2, bool all_filt, const gas_group_args &g, const gas_dev_state &st, uint32_t frames, uint32_t channel_begin, float mix_rate, float *partials, uint32_t p_offset, uint32_t p_stride, const gas_bus_args &buses) {
 	dim3 block(N_WAVES * 64);
 	if (f_pow2) {
 		if (all_filt) {
-			hipLaunchKernelGGL((k_biquad_pipe<MODE, true, true>), grid, block, 0, stream, g, st, frames, channel_begin, mix_rate, partials, p_offset, p_stride);
+			hipLaunchKernelGGL((k_biquad_pipe<MODE, true, true>), grid, block, 0, stream, g, st, frames, channel_begin, mix_rate, partials, p_offset, p_stride, buses);
 		} else {
-			hipLaunchKernelGGL((k_biquad_pipe<MODE, true, false>), grid, block, 0, stream, g, st, frames, channel_begin, mix_rate, partials, p_offset, p_stride);
+			hipLaunchKernelGGL((k_biquad_pipe<MODE, true, false>), grid, block, 0, stream, g, st, frames, channel_begin, mix_rate, partials, p_offset, p_stride, buses);
 		}
 	} else {
 		if (all_filt) {
-			hipLaunchKernelGGL((k_biquad_pipe<MODE, false, true>), grid, block, 0, stream, g, st, frames, channel_begin, mix_rate, partials, p_offset, p_stride);
+			hipLaunchKernelGGL((k_biquad_pipe<MODE, false, true>), grid, block, 0, stream, g, st, frames, channel_begin, mix_rate, partials, p_offset, p_stride, buses);
 		} else {
-			hipLaunchKernelGGL((k_biquad_pipe<MODE, false, false>), grid, block, 0, stream, g, st, frames, channel_begin, mix_rate, partials, p_offset, p_stride);
+			hipLaunchKernelGGL((k_biquad_pipe<MODE, false, false>), grid, block, 0, stream, g, st, frames, channel_begin, mix_rate, partials, p_offset, p_stride, buses);
 		}
 	}
 }
@@ -438,7 +462,7 @@ void launch_pipe(hipStream_t stream, dim3 grid, bool f_pow2, bool all_filt, cons
 
 // all_filt: the caller knows that every source of the launch takes the filter branch (FX_HIGHSHELF always does); the
 // general variant selects per lane.
-hipError_t gas_launch_biquad_pipe(hipStream_t stream, int mode, const gas_group_args &g, const gas_dev_state &st, uint32_t frames, uint32_t channel_begin, uint32_t channel_count, float mix_rate, float *partials, uint32_t p_offset, uint32_t p_stride) {
+hipError_t gas_launch_biquad_pipe(hipStream_t stream, int mode, const gas_group_args &g, const gas_dev_state &st, uint32_t frames, uint32_t channel_begin, uint32_t channel_count, float mix_rate, float *partials, uint32_t p_offset, uint32_t p_stride, const gas_bus_args &buses) {
 	if (g.n == 0) {
 		return hipSuccess;
 	}
@@ -449,13 +473,13 @@ hipError_t gas_launch_biquad_pipe(hipStream_t stream, int mode, const gas_group_
 	const bool f_pow2 = (frames & (frames - 1)) == 0;
 	switch (mode) {
 		case GAS_MODE_MIX_CHANNEL:
-			launch_pipe<GAS_MODE_MIX_CHANNEL>(stream, grid, f_pow2, false, g, st, frames, channel_begin, mix_rate, partials, p_offset, p_stride);
+			launch_pipe<GAS_MODE_MIX_CHANNEL>(stream, grid, f_pow2, false, g, st, frames, channel_begin, mix_rate, partials, p_offset, p_stride, buses);
 			break;
 		case GAS_MODE_PROCESS_FRAMES:
-			launch_pipe<GAS_MODE_PROCESS_FRAMES>(stream, grid, f_pow2, false, g, st, frames, channel_begin, mix_rate, partials, p_offset, p_stride);
+			launch_pipe<GAS_MODE_PROCESS_FRAMES>(stream, grid, f_pow2, false, g, st, frames, channel_begin, mix_rate, partials, p_offset, p_stride, buses);
 			break;
 		case GAS_MODE_FX_HIGHSHELF:
-			launch_pipe<GAS_MODE_FX_HIGHSHELF>(stream, grid, f_pow2, true, g, st, frames, channel_begin, mix_rate, partials, p_offset, p_stride);
+			launch_pipe<GAS_MODE_FX_HIGHSHELF>(stream, grid, f_pow2, true, g, st, frames, channel_begin, mix_rate, partials, p_offset, p_stride, buses);
 			break;
 		default:
 			return hipErrorInvalidValue;

@@ -201,6 +201,32 @@ int gas_hrtf_load(gas_ctx *ctx, const float *hrir, uint32_t dirs, uint32_t taps)
  * memory, *out is zero-filled. */
 int gas_process_block(gas_ctx *ctx, const gas_audio_frame *src, const uint32_t *slots, uint32_t n, uint32_t frames, gas_audio_frame *out, float *peaks, int mem);
 
+/* ---- several output buses ---------------------------------------------------------------------
+ * In the reference every playback carries a bus_volumes dictionary (spatializer_parameters.h:39-67: <= 6 buses,
+ * audio_spatializer.h:52) and AudioServer multiplies the frames a proxy returns by get_bus_map's per-channel-pair
+ * factors for each of them (audio_spatializer.cpp:274-324).  AudioSpatializer3D fills it with the dry bus -- the
+ * player's, or the Area3D's override -- at the output volume, and the area's reverb bus at reverb_volume
+ * (audio_spatializer_3d.cpp:437-461).  For a mix-channel instance the dry factor is bus/mix = 1 and the send factor
+ * is reverb_volume / mix_volume per channel pair and ear (0 where the mix volume is <= 0, :295-313).  Batched, that
+ * is: every source names the bus its dry signal goes to and (optionally) a bus that receives it scaled by `send`;
+ * one launch produces all buses:
+ *     out[b][c][i] = sum over sources with dry_bus == b of y[c][i]  +  sum over sources with send_bus == b of y[c][i] * send[c]
+ * (y = the source's mix_channel output for pair c).  GAS_KIND_3D_MIX sources only. */
+#define GAS_MAX_BUSES GAS_MAX_BUSES_PER_PLAYBACK
+#define GAS_BUS_NONE 0xffffffffu
+typedef struct gas_bus_route {
+	uint32_t dry_bus; /* index < n_buses of the call, or GAS_BUS_NONE */
+	uint32_t send_bus; /* index < n_buses, or GAS_BUS_NONE: no send */
+	float send[GAS_MAX_CHANNELS_PER_BUS][2]; /* bus_volume / mix_volume per channel pair and ear (gas_host_bus_map arithmetic) */
+} gas_bus_route;
+/* Host arrays; latest wins, snapshotted at the next gas_process_block_buses.  A slot that never got a route is
+ * {dry_bus 0, no send}.  Physics thread, like gas_params_publish. */
+int gas_bus_routes_publish(gas_ctx *ctx, const uint32_t *slots, const gas_bus_route *routes, uint32_t n);
+/* gas_process_block with out = [n_buses][C][frames] (1 <= n_buses <= GAS_MAX_BUSES).  Every source must be
+ * GAS_KIND_3D_MIX (else GAS_ERR_UNSUPPORTED_CHAIN); peaks are those of y (before any bus factor), as the reference's
+ * gate sees them (audio_spatializer.cpp:436-443). */
+int gas_process_block_buses(gas_ctx *ctx, const gas_audio_frame *src, const uint32_t *slots, uint32_t n, uint32_t frames, gas_audio_frame *out, uint32_t n_buses, float *peaks, int mem);
+
 /* ---- compatibility / parity path: the exact _process_frames and _mix_channel
  * signatures for one source (audio_spatializer.h:146,148), host pointers, synchronous. */
 int gas_process_frames_1(gas_ctx *ctx, uint32_t slot, gas_audio_frame *out, const gas_audio_frame *src, int frame_count);

@@ -1,0 +1,110 @@
+"""several output buses in one launch (gas_process_block_buses) vs AudioServer's per-bus
+multiply-accumulate of each playback's frames by get_bus_map's factors (audio_spatializer.cpp:274-324; dry bus /
+Area3D override / reverb send: audio_spatializer_3d.cpp:437-461).  The expectation is built source by source from the
+oracle's mix_channel outputs and the oracle's get_bus_map."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from helpers import TOL, rel_rms
+
+pytestmark = pytest.mark.gpu
+
+
+def oracle_bus_map(ob, smc, channel, bus_volume, mix_volumes):
+    L = ob.lib()
+    pass
+
+    out = np.zeros((4, 2), np.float32)
+    bv = np.ascontiguousarray(bus_volume, np.float32)
+    mv = np.ascontiguousarray(mix_volumes, np.float32)
+    L.gaso_bus_map(smc, channel, bv.ctypes.data, mv.ctypes.data, out.ctypes.data)
+    return out
+
+
+@pytest.mark.parametrize("n,channels,n_buses", [(70, 2, 3), (256, 1, 2), (1000, 4, 6), (9000, 1, 2)])
+def test_buses_match_per_source_bus_maps(gas, ob, n, channels, n_buses):
+    from godot_audio_spatializer_amd import synth
+
+    K = gas.capi
+    F = 512
+    rng = np.random.default_rng(n)
+    with gas.SpatializerContext(max_sources=n, frames=F, channel_count=channels) as ctx:
+        slots = ctx.source_alloc_many(n, K.KIND_3D_MIX)
+        oracles = [ob.BatchOracle(ob.KIND_3D_MIX, 1, F, channel_count=channels) for _ in range(n)] if n <= 1000 else None
+        whole = ob.BatchOracle(ob.KIND_3D_MIX, n, F, channel_count=channels)
+        for cb in range(3):
+            p = synth.draw_params(rng, n, channel_count=channels, frames=F)
+            p["mix_volumes"][::11] = 0.0  # silent pairs: the send is 0 there (mix volume <= 0, :300-305)
+            # reverb send volumes per source and pair (what calculate_spatialization's reverb_vol would give)
+            reverb = (p["mix_volumes"] * rng.uniform(0.0, 1.5, (n, 1, 1))).astype(np.float32)
+            routes = np.zeros(n, K.BUS_ROUTE_DTYPE)
+            routes["dry_bus"] = rng.integers(0, n_buses, n)  # the player's bus or an Area3D override
+            routes["send_bus"] = np.where(rng.uniform(size=n) < 0.6, rng.integers(0, n_buses, n), K.BUS_NONE)
+            for s in range(n):
+                for c in range(channels):
+                    routes["send"][s, c] = oracle_bus_map(ob, 1, c, reverb[s], p["mix_volumes"][s])[c]
+            ctx.params_publish_batch(slots, p)
+            ctx.bus_routes_publish(slots, routes)
+            src = synth.draw_sources(rng, n, F)
+            got, peaks = ctx.process_block_buses(src, slots, n_buses)
+            _, wpeaks, w64 = whole.block(p.astype(ob.PARAMS_DTYPE), src, want64=True)
+            np.testing.assert_allclose(peaks, wpeaks, rtol=2e-5, atol=1e-7)  # the gate sees y, not a bus
+            if oracles is None:
+                # full size: the buses must add up to what they were split from when every send is dropped
+                routes["send_bus"] = K.BUS_NONE
+                continue
+            want = np.zeros((n_buses, channels, F, 2), np.float64)
+            for s in range(n):
+                _, _, y = oracles[s].block(p[s:s + 1].astype(ob.PARAMS_DTYPE), src[s:s + 1], want64=True)
+                y32 = y[:channels].astype(np.float32)
+                want[routes["dry_bus"][s]] += y32
+                if routes["send_bus"][s] != K.BUS_NONE:
+                    for c in range(channels):
+                        want[routes["send_bus"][s], c] += (y32[c] * routes["send"][s, c][None, :]).astype(np.float32)  # [ENGINE] AudioServer: frame * volume, f32
+            for b in range(n_buses):
+                for c in range(channels):
+                    if np.abs(want[b, c]).max() > 0:
+                        assert rel_rms(got[b, c], want[b, c]) <= TOL, (cb, b, c)
+                    else:
+                        assert not got[b, c].any()
+
+
+def test_buses_without_sends_sum_to_the_single_mix(gas):
+    from godot_audio_spatializer_amd import synth
+
+    K = gas.capi
+    n, F = 3000, 512
+    rng = np.random.default_rng(4)
+    p = synth.draw_params(rng, n, frames=F)
+    src = synth.draw_sources(rng, n, F)
+    routes = np.zeros(n, K.BUS_ROUTE_DTYPE)
+    routes["dry_bus"] = rng.integers(0, 4, n)
+    routes["send_bus"] = K.BUS_NONE
+    outs = []
+    for buses in (True, False):
+        with gas.SpatializerContext(max_sources=n, frames=F) as ctx:
+            slots = ctx.source_alloc_many(n, K.KIND_3D_MIX)
+            ctx.params_publish_batch(slots, p)
+            if buses:
+                ctx.bus_routes_publish(slots, routes)
+                outs.append(ctx.process_block_buses(src, slots, 4)[0].astype(np.float64).sum(axis=0))
+            else:
+                outs.append(ctx.process_block(src, slots)[0].astype(np.float64))
+    assert rel_rms(outs[0][0], outs[1][0]) <= TOL
+
+
+def test_buses_reject_other_kinds_and_bad_counts(gas):
+    K = gas.capi
+    with gas.SpatializerContext(max_sources=2, frames=512) as ctx:
+        s = ctx.source_alloc(K.KIND_EFFECT)
+        ctx.params_publish(s, np.zeros(1, K.PARAMS_DTYPE))
+        with pytest.raises(gas.GasError) as ei:
+            ctx.process_block_buses(np.zeros((1, 512, 2), np.float32), [s], 2)
+        assert ei.value.status == -6
+        with pytest.raises(gas.GasError) as ei:
+            ctx.process_block_buses(np.zeros((0, 512, 2), np.float32), [], 7)
+        assert ei.value.status == -1
+        out, _ = ctx.process_block_buses(np.zeros((0, 512, 2), np.float32), [], 3)
+        assert out.shape == (3, 1, 512, 2) and not out.any()
