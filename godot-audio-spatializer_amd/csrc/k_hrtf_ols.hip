@@ -23,8 +23,12 @@
 // lane-major table (16 B/lane, L2/Infinity-Cache resident).  Waves of a workgroup combine through LDS
 // into one partial mix; k_mix_reduce adds the partials in fixed order (no float atomics).
 //
-// Bound: HBM.  Algorithmic bytes/source = F*8 (source) + 2*hist_len*4 (history r+w) + 128 (params) + 8
-// (peak) + 8 (gain state), + the ring traffic (8 taps * F * 8 read + F * 8 write) with early reflections.
+// Bound: HBM.  Algorithmic bytes/source as group_bytes() (gas_ctx.hip) counts them: F*8 (source) + 2*hist_len*4
+// (history read + write) + 24 (hrtf_gain + hrtf_dir read, previous gain read + write, peak write), + the ring
+// traffic (8 taps * F * 8 read + F * 8 write) and the 8 gains + 8 delays with early reflections; the HRIR spectra
+// table and the output mix are counted once per launch, not per source.  (The full 128-byte gas_params row is NOT
+// part of the figure: the kernel reads its two HRTF fields, one 8-byte load.)  This file keeps the forms with
+// crossfade / direction runs / early reflections / per-source rows; the plain [HRTF] callback runs k_hrtf_uni.hip.
 #include "gas_hrtf_wave.h"
 
 namespace {
