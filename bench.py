@@ -310,6 +310,7 @@ def main():
     ap.add_argument("--no-pipelined-mix", action="store_true", help="headline without GAS_FLAG_PIPELINED_MIX: the partial-mix sum of callback t runs before callback t+1's DSP kernel instead of under it")
     ap.add_argument("--direction-order", action="store_true", help="GAS_FLAG_DIRECTION_ORDER: let the library group sources by HRIR direction (device sort per publish)")
     ap.add_argument("--presorted-directions", action="store_true", help="GAS_FLAG_DIRECTION_RUNS with parameters whose HRIR directions are grouped in callback order (what a caller that sorts its list gets)")
+    ap.add_argument("--xcd-order", action="store_true", help="GAS_FLAG_XCD_ORDER: XCD-affine processing order rebuilt on the device after every publish (experiment: fewer L2 fills, no net gain)")
     ap.add_argument("--xcd-directions", action="store_true", help="experiment: draw each source's HRIR direction from the eighth of the table that belongs to its workgroup's XCD (upper bound of an XCD-aware source partition)")
     ap.add_argument("--draining-every", type=int, default=64, help="1 source in N has ended its stream (exact peak needed, audio_spatializer.cpp:464-469); 0 = none")
     ap.add_argument("--exact-peaks", action="store_true", help="headline with the exact peak of every source")
@@ -360,6 +361,8 @@ def main():
         base_flags |= K.FLAG_DIRECTION_ORDER
     if args.presorted_directions:
         base_flags |= K.FLAG_DIRECTION_RUNS
+    if args.xcd_order:
+        base_flags |= K.FLAG_XCD_ORDER
     head_flags = base_flags | (0 if args.no_pipelined_mix else K.FLAG_PIPELINED_MIX)
 
     # ---- headline pass: exactly --steps callbacks, no markers inside -----------------------------------------------

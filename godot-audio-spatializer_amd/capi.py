@@ -27,6 +27,7 @@ FLAG_HRTF_CROSSFADE = 2
 FLAG_DIRECTION_ORDER = 4
 FLAG_PIPELINED_MIX = 8
 FLAG_DIRECTION_RUNS = 16
+FLAG_XCD_ORDER = 32
 
 STATUS = {
     0: "GAS_OK",
@@ -162,6 +163,7 @@ EXPORTS = [
     "gas_profile_enable",
     "gas_profile_read",
     "gas_bandwidth_probe",
+    "gas_ctx_read_hrtf_order",
 ]
 
 
@@ -235,6 +237,7 @@ def load_library():
     L.gas_profile_enable.argtypes = [vp, i32]
     L.gas_profile_read.argtypes = [vp, C.POINTER(Profile), i32]
     L.gas_bandwidth_probe.argtypes = [vp, C.c_uint64, C.c_uint64, u32, u32, u32, C.POINTER(C.c_double)]
+    L.gas_ctx_read_hrtf_order.argtypes = [vp, vp, u32]
     _lib = L
     return L
 
@@ -453,6 +456,12 @@ class SpatializerContext:
         us = C.c_double()
         self._check(self.lib.gas_bandwidth_probe(self.h, int(read_bytes), int(write_bytes), int(workgroups), int(unroll), int(iters), C.byref(us)), "gas_bandwidth_probe")
         return us.value
+
+    def read_hrtf_order(self, n):
+        """Diagnostic: the XCD-affine processing order of the last callback's plain [HRTF] sources."""
+        out = np.zeros(int(n), np.uint32)
+        self._check(self.lib.gas_ctx_read_hrtf_order(self.h, out.ctypes.data, int(n)), "gas_ctx_read_hrtf_order")
+        return out
 
     def profile_read(self, reset=True):
         p = Profile()

@@ -107,6 +107,8 @@ struct gas_ctx {
 	uint32_t *d_order = nullptr; // [max_sources] direction order of the frequency-domain HRTF groups (k_dir_order)
 	uint64_t order_groups_gen = UINT64_MAX, order_params_gen = 0; // what d_order was built from
 	bool order_ok[G_COUNT] = {}; // d_order holds this group's order
+	uint32_t xcd_order_auto_min = GAS_XCD_ORDER_AUTO_MIN; // GAS_XCD_ORDER_AUTO_MIN in the environment overrides (experiments)
+	bool last_uni_ordered = false; // the last k_hrtf_uni launch ran in k_xcd_order's order
 	uint64_t stream_groups_gen = UINT64_MAX; // groups_gen the stream path's cached list corresponds to
 	bool cached_identity_rows = true;
 	Group groups[G_COUNT];
@@ -493,6 +495,21 @@ int run_groups(gas_ctx *c, const gas_audio_frame *d_src, const uint32_t *d_slots
 				const gas_params *fresh = fd_gt == G_FX_HRTF ? c->fresh_for_launch : nullptr;
 				if (gt == G_FX_HRTF && gp.count == 0 && uni_hrtf) {
 					// the whole plain-[HRTF] group in one uniform launch (k_hrtf_uni.hip)
+					// XCD-affine processing order (k_xcd_order): rebuilt when the list or any parameter changed, else reused
+					const uint32_t uni_wgs = gas_hrtf_uni_partials(g_fd.n);
+					c->last_uni_ordered = false;
+					if (use_order && ((c->cfg.flags & GAS_FLAG_XCD_ORDER) != 0 || g_fd.n >= c->xcd_order_auto_min) && uni_wgs % 8 == 0 && c->tab.dirs >= 8) {
+						if (!c->d_order) {
+							GAS_HIP(c, hipMalloc(&c->d_order, (size_t)c->cfg.max_sources * sizeof(uint32_t)));
+						}
+						uint32_t *ord = c->d_order + groups[fd_gt].offset;
+						if (!c->order_ok[fd_gt]) {
+							GAS_HIP(c, gas_launch_xcd_order(c->stream, g_fd, c->st.params, fresh, c->tab.dirs, uni_wgs, gas_hrtf_uni_waves(), ord));
+							c->order_ok[fd_gt] = true;
+						}
+						g_fd.order = ord;
+						c->last_uni_ordered = true;
+					}
 					e = gas_launch_hrtf_uni(c->stream, g_fd, c->uni_peak_any && !c->uni_peak_all ? c->d_peak_bits : nullptr, c->uni_peak_all, c->st, c->tab, c->d_tw, F, c->hist_len, parts, p_off, c->fused_streams ? c->d_cursors : nullptr, c->d_fade_env, fresh, job);
 					carried_bytes = job.partials ? ((uint64_t)job.p_count + 1) * job.elems * sizeof(float) : 0;
 					job = gas_deferred_reduce();
@@ -935,6 +952,9 @@ int gas_ctx_create(const gas_config *cfg, gas_ctx **out_ctx) {
 	}
 	c->cfg = *cfg;
 	c->hist_len = 512 - cfg->frames / 2;
+	if (const char *v = std::getenv("GAS_XCD_ORDER_AUTO_MIN")) {
+		c->xcd_order_auto_min = (uint32_t)std::strtoul(v, nullptr, 10);
+	}
 	const size_t N = cfg->max_sources;
 	int rc = [&]() -> int {
 		GAS_HIP(c, hipSetDevice(cfg->device));
@@ -2031,6 +2051,19 @@ int gas_profile_enable(gas_ctx *c, int on) {
 	c->profiling = on != 0;
 	c->prof_every = on > 1 ? (uint32_t)on : 1; // on = N > 1: bracket every Nth callback only (the markers cost throughput)
 	c->prof_tick = 0;
+	return GAS_OK;
+}
+
+int gas_ctx_read_hrtf_order(gas_ctx *c, uint32_t *out, uint32_t n) {
+	if (!c || !out) {
+		return GAS_ERR_INVALID_ARGUMENT;
+	}
+	if (!c->d_order || !c->order_ok[G_FX_HRTF] || !c->last_uni_ordered || n > c->groups[G_FX_HRTF].count) {
+		return GAS_ERR_INVALID_ARGUMENT;
+	}
+	GAS_HIP(c, hipSetDevice(c->cfg.device));
+	GAS_HIP(c, hipStreamSynchronize(c->stream));
+	GAS_HIP(c, hipMemcpy(out, c->d_order + c->groups[G_FX_HRTF].offset, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost));
 	return GAS_OK;
 }
 

@@ -58,7 +58,7 @@ struct gas_group_args {
 	uint32_t slot_base;
 	uint32_t n;
 	float *peaks; // [n_rows_total][2]
-	const uint32_t *order = nullptr; // [n] k_hrtf_ols only: processing order (entries grouped by HRIR direction), or nullptr = entry order
+	const uint32_t *order = nullptr; // [n] processing order (k_hrtf_ols: entries grouped by HRIR direction; k_hrtf_uni: XCD-affine, k_xcd_order), or nullptr = entry order
 };
 
 // GAS_FLAG_PIPELINED_MIX: the final sum of the PREVIOUS callback's partial mixes (exactly k_mix_reduce's job for one
@@ -128,5 +128,9 @@ hipError_t gas_launch_stream_probe(hipStream_t stream, const void *rd, uint64_t 
 #define GAS_DIR_ORDER_SEGMENT 8192
 #define GAS_DIR_ORDER_MIN_SOURCES 512
 bool gas_dir_order_supported(uint32_t dirs);
+// k_xcd_order (k_misc.hip): XCD-affine processing order for a k_hrtf_uni launch of hrtf_wgs workgroups (multiple of 8)
+#define GAS_XCD_ORDER_AUTO_MIN 0xFFFFFFFFu // callbacks of at least this many sources are ordered without the flag: never (measured: no net gain at any size); the environment variable of the same name overrides for experiments
+hipError_t gas_launch_xcd_order(hipStream_t stream, const gas_group_args &g, const gas_params *params, const gas_params *fresh, uint32_t dirs, uint32_t hrtf_wgs, uint32_t waves_per_wg, uint32_t *order);
+uint32_t gas_hrtf_uni_waves();
 hipError_t gas_launch_dir_order(hipStream_t stream, const gas_group_args &g, const gas_params *params, const gas_params *fresh, uint32_t dirs, uint32_t *order);
 hipError_t gas_launch_zero_slot(hipStream_t stream, const gas_dev_state &st, uint32_t slot, uint32_t hist_len, uint32_t er_ring_frames);

@@ -47,6 +47,13 @@ namespace {
 #define GAS_UNI_WAVES 8
 #endif
 constexpr int UW = GAS_UNI_WAVES;
+#ifndef GAS_UNI_DEPTH
+#define GAS_UNI_DEPTH 1 // sources whose frames + history are in flight per wave (landing register sets)
+#endif
+constexpr int UD = GAS_UNI_DEPTH;
+#ifndef GAS_UNI_UNIFORM_NEXT
+#define GAS_UNI_UNIFORM_NEXT 0 // 1: request the next source's data on EVERY trip of the source loop (exact vmcnt waits; measured 0.4 us slower, see there)
+#endif
 constexpr bool LEAN = UW > 8;
 constexpr int UNI_SLICES = LEAN ? 1 : 2; // exchange slices per wave in the source loop
 
@@ -95,13 +102,19 @@ __global__ __launch_bounds__(UW * 64, LEAN ? 3 : GAS_HRTF_WAVES_PER_SIMD) void k
 	wave_range(g.n, blockIdx.x * UW + wave, gridDim.x * UW, first, last);
 	const bool have = first + lane < last; // <= 64 sources per wave (gas_hrtf_plan): one metadata lane per source
 	LaneMeta lm{};
+	uint32_t my_entry = first + lane; // list entry this lane's source is (g.order: XCD-affine processing order, k_xcd_order)
 	if (have) {
-		const uint32_t e = first + lane;
+		if (g.order) {
+			my_entry = g.order[first + lane];
+		}
+		const uint32_t e = my_entry;
 		lm.slot = g.slots ? g.slots[e] : g.slot_base + e; // a contiguous slot range in row order needs no list at all
 		lm.row = g.rows ? g.rows[e] : e;
 	}
 	gas_audio_frame raw[FQ]; // frames lane + 64 q of the source in flight
 	float rawh[HQ]; // its history samples (lane-major rows: one 16-byte access per lane at F = 512)
+	gas_audio_frame rawB[UD > 1 ? FQ : 1]; // UD == 2: a second landing set, the source after that one
+	float rawhB[UD > 1 ? HQ : 1];
 	if (first < last) { // wave-uniform
 		SrcMeta m0{};
 		m0.slot = (uint32_t)__builtin_amdgcn_readlane((int)lm.slot, 0);
@@ -109,6 +122,15 @@ __global__ __launch_bounds__(UW * 64, LEAN ? 3 : GAS_HRTF_WAVES_PER_SIMD) void k
 		load_history<HQ>(st.hrtf_hist + (size_t)m0.slot * HL, lane, rawh);
 		if constexpr (!SRC_PCM) {
 			load_window<false, FQ>(g, m0, lane, fade_env, raw);
+		}
+	}
+	if constexpr (UD > 1 && !SRC_PCM) {
+		if (first + 1 < last) {
+			SrcMeta m1{};
+			m1.slot = (uint32_t)__builtin_amdgcn_readlane((int)lm.slot, 1);
+			m1.row = (uint32_t)__builtin_amdgcn_readlane((int)lm.row, 1);
+			load_history<HQ>(st.hrtf_hist + (size_t)m1.slot * HL, lane, rawhB);
+			load_window<false, FQ>(g, m1, lane, fade_env, rawB);
 		}
 	}
 	uint32_t my_flag = 0; // this lane's source needs its exact peak
@@ -123,7 +145,7 @@ __global__ __launch_bounds__(UW * 64, LEAN ? 3 : GAS_HRTF_WAVES_PER_SIMD) void k
 		if constexpr (SRC_PCM) {
 			lm.cur = cursors[lm.slot];
 		}
-		const uint32_t e = first + lane;
+		const uint32_t e = my_entry;
 		my_flag = peak_all ? 1u : (peak_bits ? (peak_bits[e >> 5] >> (e & 31)) & 1u : 0u);
 	}
 	if constexpr (SRC_PCM) {
@@ -260,22 +282,25 @@ __global__ __launch_bounds__(UW * 64, LEAN ? 3 : GAS_HRTF_WAVES_PER_SIMD) void k
 		}
 	};
 
+	constexpr uint32_t AHEAD = (UD > 1 && !SRC_PCM) ? 2 : 1; // the landing set freed by source e is refilled with source e + AHEAD
 	for (uint32_t e = first; e < last; e++) {
-		const bool has_next = e + 1 < last;
+		const bool use_b = AHEAD == 2 && ((e - first) & 1u) != 0; // wave-uniform: which landing set holds source e
+		const bool has_next = e + AHEAD < last;
 		const SrcMeta m = bcast_meta<SRC_PCM>(lm, e - first, F);
-		const SrcMeta mn = bcast_meta<SRC_PCM>(lm, has_next ? e + 1 - first : e - first, F);
+		const SrcMeta mn = bcast_meta<SRC_PCM>(lm, has_next ? e + AHEAD - first : e - first, F);
 		const uint32_t flag = (uint32_t)__builtin_amdgcn_readlane((int)my_flag, (int)(e - first));
 
 		// x_full[lane + 64 q]: q < HQ from the history, the rest from this callback's frames
 		float xq[NQ];
 #pragma unroll
 		for (int q = 0; q < HQ; q++) {
-			xq[q] = rawh[q];
+			xq[q] = use_b ? rawhB[UD > 1 ? q : 0] : rawh[q];
 		}
 #pragma unroll
 		for (int q = 0; q < FQ; q++) {
 			const int f = lane + 64 * q;
-			const float mono = (raw[q].left + raw[q].right) * 0.5f;
+			const gas_audio_frame rq = use_b ? rawB[UD > 1 ? q : 0] : raw[q];
+			const float mono = (rq.left + rq.right) * 0.5f;
 			xq[HQ + q] = mono * (m.g1 * tq[q] + omtq[q] * m.g0);
 			(void)f;
 		}
@@ -293,9 +318,50 @@ __global__ __launch_bounds__(UW * 64, LEAN ? 3 : GAS_HRTF_WAVES_PER_SIMD) void k
 				}
 			}
 		}
-		if (has_next) { // the landing registers are free again: the next source's history and frames
-			load_history<HQ>(st.hrtf_hist + (size_t)mn.slot * HL, lane, rawh);
-			load_window<SRC_PCM, FQ>(g, mn, lane, fade_env, raw);
+		if constexpr (!SRC_PCM && GAS_UNI_UNIFORM_NEXT) {
+			// EXPERIMENT (off): the next source's history and frames requested on EVERY trip -- the last one re-reads the
+			// (L2-resident) twiddle table into registers nobody uses -- so that the loop body has no branch around its
+			// loads.  With the branch the compiler, which counts vmcnt per path and takes the smallest count at a join,
+			// waits for the HRIR row with vmcnt(4..1), i.e. also for most of the frames it has just requested; without it
+			// the waits are exact (vmcnt(13..10)).  Measured: no gain (15.6 -> 16.1 us at 8192 sources, 90.3 -> 90.0 at
+			// 65536) -- the frames' flight is not what a trip waits for (profiles/r02_notes.md); GAS_UNI_DEPTH=2 (a second
+			// landing set, two sources in flight per wave) likewise: 16.5 / 92 us.
+			const gas_audio_frame *nsrc = has_next ? g.src + (size_t)mn.row * F : reinterpret_cast<const gas_audio_frame *>(tw);
+			const float *nhist = has_next ? st.hrtf_hist + (size_t)mn.slot * HL : reinterpret_cast<const float *>(tw);
+			if constexpr (AHEAD == 2) {
+				if (use_b) {
+					load_history<HQ>(nhist, lane, rawhB);
+#pragma unroll
+					for (int q = 0; q < FQ; q++) {
+						rawB[UD > 1 ? q : 0] = nt_load_frame(nsrc + lane + 64 * q);
+					}
+				} else {
+					load_history<HQ>(nhist, lane, rawh);
+#pragma unroll
+					for (int q = 0; q < FQ; q++) {
+						raw[q] = nt_load_frame(nsrc + lane + 64 * q);
+					}
+				}
+			} else {
+				load_history<HQ>(nhist, lane, rawh);
+#pragma unroll
+				for (int q = 0; q < FQ; q++) {
+					raw[q] = nt_load_frame(nsrc + lane + 64 * q);
+				}
+			}
+		} else if (has_next) {
+			if constexpr (AHEAD == 2) {
+				if (use_b) {
+					load_history<HQ>(st.hrtf_hist + (size_t)mn.slot * HL, lane, rawhB);
+					load_window<SRC_PCM, FQ>(g, mn, lane, fade_env, rawB);
+				} else {
+					load_history<HQ>(st.hrtf_hist + (size_t)mn.slot * HL, lane, rawh);
+					load_window<SRC_PCM, FQ>(g, mn, lane, fade_env, raw);
+				}
+			} else {
+				load_history<HQ>(st.hrtf_hist + (size_t)mn.slot * HL, lane, rawh);
+				load_window<SRC_PCM, FQ>(g, mn, lane, fade_env, raw);
+			}
 		}
 		// z = a + i b : a = x_full[0..512), b = x_full[S..S+512) -- one complex FFT serves both sub-blocks
 		float2 zs[8];
@@ -411,6 +477,10 @@ __global__ __launch_bounds__(UW * 64, LEAN ? 3 : GAS_HRTF_WAVES_PER_SIMD) void k
 } // namespace
 
 // One workgroup per CU (one residency round), at least one source per wave, at most 64 (one metadata lane each).
+uint32_t gas_hrtf_uni_waves() {
+	return UW;
+}
+
 uint32_t gas_hrtf_uni_partials(uint32_t n) {
 	const uint32_t want = (n + UW - 1) / UW, need = (n + UW * 64 - 1) / (UW * 64);
 	const uint32_t round = UW < 8 ? 256u * (8 / UW) : 256u; // workgroups resident at once
@@ -422,7 +492,7 @@ hipError_t gas_launch_hrtf_uni(hipStream_t stream, const gas_group_args &g, cons
 	if (g.n == 0) {
 		return hipSuccess;
 	}
-	if (frames % 128 != 0 || frames > 512 || hist_len != 512 - frames / 2 || g.order != nullptr) {
+	if (frames % 128 != 0 || frames > 512 || hist_len != 512 - frames / 2) {
 		return hipErrorInvalidValue;
 	}
 	const uint32_t wgs = gas_hrtf_uni_partials(g.n);

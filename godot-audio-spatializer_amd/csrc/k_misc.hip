@@ -239,6 +239,155 @@ __global__ __launch_bounds__(DIR_WAVES * 64) void k_dir_order(gas_group_args g, 
 	}
 }
 
+
+// k_xcd_order -- XCD-affine processing order for k_hrtf_uni (DESIGN.md 3.1 "table locality").
+// Workgroup b of a launch runs on XCD b % 8, and every XCD has its own 4 MiB L2: with random directions each XCD pulls
+// its own copy of (nearly) every HRIR spectra row it touches, which at 8192 sources is 20 MB of L2 fills on top of 54 MB
+// of algorithmic bytes and at 65536 sources thrashes the L2 outright (measured 1.46x, profiles/r02_*).  This kernel
+// permutes the callback's entries so that the sources whose direction lies in eighth k of the table are processed by
+// workgroups b = k (mod 8): every XCD then keeps touching the same 1/8 of the table.
+//
+// One workgroup per SEGMENT of eight consecutive k_hrtf_uni workgroups (one per XCD).  A segment's entries are a
+// contiguous range of the list; bucket k's entries fill workgroup 8 s + k's range in list order; what does not fit
+// (buckets are never exactly equal) fills the holes the short buckets leave, in list order too.  Stable counting sort,
+// no atomics: the order -- and with it the floating-point summation order of the mix -- is a pure function of the
+// list and the directions.  The segment is walked in tiles of one entry per thread (every direction of a tile is one
+// parallel round trip: a first version with a sequential chunk per thread took 16 us at 65536 sources, all of it load
+// latency); pass 1 counts the buckets, pass 2 ranks (ballots within a wave, LDS across waves, a running base across
+// tiles) and places.
+constexpr int XO_WAVES = 16;
+constexpr int XO_THREADS = XO_WAVES * 64;
+
+__device__ __forceinline__ uint32_t xo_first(uint32_t gw, uint32_t base, uint32_t rem) { // wave_range()'s first
+	return gw * base + (gw < rem ? gw : rem);
+}
+
+__global__ __launch_bounds__(XO_THREADS) void k_xcd_order(gas_group_args g, const gas_params *__restrict__ params, const gas_params *__restrict__ fresh, uint32_t dirs, uint32_t n_waves, uint32_t waves_per_wg, uint32_t *__restrict__ order) {
+	// the bucket tables live in LDS and are read by bucket number (eight distinct addresses per wave: broadcasts); as
+	// per-thread arrays they cost 190 spilled VGPRs at 1024 threads
+	__shared__ uint32_t wcnt[XO_WAVES][8]; // per-wave bucket counts (pass 1: of the segment, pass 2: of the current tile)
+	__shared__ uint32_t wpre[XO_WAVES][8]; // pass 2: entries of bucket j in the lower waves of the tile
+	__shared__ uint32_t start[9], quota[8], count[8], over_pre[8], hole_pre[9], seen[8];
+	const uint32_t t = threadIdx.x;
+	const int lane = t & 63, wave = t >> 6;
+	const uint32_t base = g.n / n_waves, rem = g.n % n_waves;
+	const uint32_t wg0 = blockIdx.x * 8; // first k_hrtf_uni workgroup of this segment
+	const uint32_t A = xo_first(wg0 * waves_per_wg, base, rem), S = xo_first((wg0 + 8) * waves_per_wg, base, rem) - A;
+	if (t < 9) {
+		start[t] = xo_first((wg0 + t) * waves_per_wg, base, rem);
+	}
+	// bucket of list entry A + i (i < S), 8 for i >= S: every load unconditional, masked afterwards
+	auto bucket_of = [&](uint32_t i) -> uint32_t {
+		const uint32_t e = A + (i < S ? i : 0);
+		const uint32_t slot = g.slots ? g.slots[e] : g.slot_base + e;
+		const uint32_t row = g.rows ? g.rows[e] : e;
+		const gas_params *P = fresh ? fresh + row : params + slot;
+		uint32_t d = P->hrtf_dir;
+		d = d < dirs ? d : 0; // the clamp of k_hrtf_uni
+		const uint32_t k = d * 8u / dirs;
+		return i < S ? (k < 8 ? k : 7) : 8u;
+	};
+	// this wave's count of bucket `lane` (lanes 0..7) among the 64 values k
+	auto wave_counts = [&](uint32_t k) -> uint32_t {
+		uint32_t wv = 0;
+#pragma unroll
+		for (int j = 0; j < 8; j++) {
+			const uint32_t c = (uint32_t)__popcll(__ballot(k == (uint32_t)j));
+			wv = lane == j ? c : wv;
+		}
+		return wv;
+	};
+	// ---- pass 1: bucket totals of the segment (four tiles' loads in flight per trip) -----------------------------
+	uint32_t mine = 0; // lanes 0..7: this wave's entries of bucket `lane`
+	for (uint32_t i0 = 0; i0 < S; i0 += 4 * XO_THREADS) {
+		uint32_t k4[4];
+#pragma unroll
+		for (int u = 0; u < 4; u++) {
+			k4[u] = bucket_of(i0 + u * XO_THREADS + t);
+		}
+#pragma unroll
+		for (int u = 0; u < 4; u++) {
+			mine += wave_counts(k4[u]);
+		}
+	}
+	if (lane < 8) {
+		wcnt[wave][lane] = mine;
+	}
+	__syncthreads();
+	if (t == 0) { // quotas, the overflow of the long buckets and the holes of the short ones
+		uint32_t ov = 0, ho = 0;
+		for (int k = 0; k < 8; k++) {
+			uint32_t c = 0;
+			for (int w = 0; w < XO_WAVES; w++) {
+				c += wcnt[w][k];
+			}
+			const uint32_t q = start[k + 1] - start[k];
+			quota[k] = q;
+			count[k] = c;
+			over_pre[k] = ov;
+			hole_pre[k] = ho;
+			seen[k] = 0;
+			ov += c > q ? c - q : 0u;
+			ho += c < q ? q - c : 0u;
+		}
+		hole_pre[8] = ho;
+	}
+	// ---- pass 2: rank and place, tile by tile ----------------------------------------------------------------------
+	const uint64_t lt = (1ull << lane) - 1;
+	for (uint32_t i0 = 0; i0 < S; i0 += 2 * XO_THREADS) {
+		uint32_t k2[2];
+#pragma unroll
+		for (int u = 0; u < 2; u++) {
+			k2[u] = bucket_of(i0 + u * XO_THREADS + t);
+		}
+#pragma unroll
+		for (int u = 0; u < 2; u++) {
+			const uint32_t i = i0 + u * XO_THREADS + t;
+			const uint32_t k = k2[u];
+			uint32_t before = 0;
+#pragma unroll
+			for (int j = 0; j < 8; j++) {
+				const uint64_t m = __ballot(k == (uint32_t)j);
+				before = k == (uint32_t)j ? (uint32_t)__popcll(m & lt) : before;
+			}
+			const uint32_t wv = wave_counts(k);
+			__syncthreads(); // the previous tile's tables have been read (and thread 0's tables are written)
+			if (lane < 8) {
+				wcnt[wave][lane] = wv;
+			}
+			__syncthreads();
+			if (t < XO_WAVES * 8) { // thread (w, j): bucket j's entries in the waves below w
+				const uint32_t w = t >> 3, j = t & 7;
+				uint32_t lower = 0;
+				for (uint32_t x = 0; x < w; x++) {
+					lower += wcnt[x][j];
+				}
+				wpre[w][j] = lower;
+			}
+			__syncthreads();
+			if (k < 8) {
+				const uint32_t r = seen[k] + wpre[wave][k] + before, q = quota[k];
+				uint32_t pos;
+				if (r < q) {
+					pos = start[k] + r;
+				} else {
+					const uint32_t o = over_pre[k] + (r - q); // this entry's number among the overflowing ones
+					uint32_t j = 0;
+					while (j < 7 && o >= hole_pre[j + 1]) {
+						j++;
+					}
+					pos = start[j] + count[j] + (o - hole_pre[j]);
+				}
+				order[pos] = A + i;
+			}
+			__syncthreads(); // everyone has read seen[]
+			if (t < 8) {
+				seen[t] += wpre[XO_WAVES - 1][t] + wcnt[XO_WAVES - 1][t];
+			}
+		}
+	}
+}
+
 } // namespace
 
 hipError_t gas_launch_stream_probe(hipStream_t stream, const void *rd, uint64_t rd_bytes, void *wr, uint64_t wr_bytes, uint32_t workgroups, uint32_t unroll, float *sink) {
@@ -263,6 +412,17 @@ hipError_t gas_launch_stream_probe(hipStream_t stream, const void *rd, uint64_t 
 
 hipError_t gas_launch_noop(hipStream_t stream) {
 	hipLaunchKernelGGL(k_noop, dim3(1), dim3(64), 0, stream);
+	return hipGetLastError();
+}
+
+hipError_t gas_launch_xcd_order(hipStream_t stream, const gas_group_args &g, const gas_params *params, const gas_params *fresh, uint32_t dirs, uint32_t hrtf_wgs, uint32_t waves_per_wg, uint32_t *order) {
+	if (g.n == 0) {
+		return hipSuccess;
+	}
+	if (hrtf_wgs % 8 != 0 || dirs < 8) {
+		return hipErrorInvalidValue;
+	}
+	hipLaunchKernelGGL(k_xcd_order, dim3(hrtf_wgs / 8), dim3(XO_THREADS), 0, stream, g, params, fresh, dirs, hrtf_wgs * waves_per_wg, waves_per_wg, order);
 	return hipGetLastError();
 }
 

@@ -124,6 +124,14 @@ typedef struct gas_config {
  * results are bitwise identical to the ordered mode.  A synchronous audio callback gains nothing from it. */
 #define GAS_FLAG_PIPELINED_MIX 8u
 #define GAS_FLAG_DIRECTION_RUNS 16u /* see GAS_FLAG_DIRECTION_ORDER */
+/* XCD-affine processing order for plain [HRTF] callbacks (>= 2048 sources): after every parameter publish or list
+ * change one small launch (k_xcd_order) permutes the callback's sources so that each of the GPU's eight XCDs (own L2
+ * each) keeps working on the same eighth of the HRIR spectra table.  MEASURED (profiles/r02_notes.md): L2 fills drop
+ * from 1.46x to 1.05x of the algorithmic bytes at 65536 sources, but the kernel gains only 4 % (the rows are then read
+ * in scattered instead of list order) and the ordering launch costs more than that -- so it is OFF unless asked for;
+ * kept because it answers what the excess traffic costs.  The mix is the same sum in another (still deterministic)
+ * order: results agree to f32 rounding, not bitwise, with the unordered launch. */
+#define GAS_FLAG_XCD_ORDER 32u
 
 /* SpatializerParameters (spatializer_parameters.h:39-67) + SpatializerParameters3D
  * (audio_spatializer_3d.h:61-83) as one 128-byte POD, plus the per-block effect
@@ -338,6 +346,10 @@ int gas_profile_read(gas_ctx *ctx, gas_profile *out, int reset);
  * calibration as the dominant kernel; *out_us = average span of one launch on the GPU timeline over `iters` launches.
  * workgroups x 256 threads, `unroll` (1, 2, 4 or 8) independent loads in flight per thread. */
 int gas_bandwidth_probe(gas_ctx *ctx, uint64_t read_bytes, uint64_t write_bytes, uint32_t workgroups, uint32_t unroll, uint32_t iters, double *out_us);
+/* Diagnostic: the processing order the last gas_process_block used for its plain [HRTF] sources (GAS_FLAG_XCD_ORDER
+ * only): out[i] = list entry processed i-th; waits for the stream.  GAS_ERR_INVALID_ARGUMENT when that
+ * callback ran in list order. */
+int gas_ctx_read_hrtf_order(gas_ctx *ctx, uint32_t *out, uint32_t n);
 
 #ifdef __cplusplus
 }
