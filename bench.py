@@ -52,7 +52,7 @@ N_SRC_BUFFERS_BYTES = int(os.environ.get("GAS_BENCH_SRC_BYTES", 320 << 20))  # r
 CONDITION_STEPS = 64  # untimed callbacks in front of the --warmup ones: clocks and caches settle independently of --warmup
 
 
-def pmc_traffic(kernel, workload, n_local, peaks, pipelined):
+def pmc_traffic(kernel, workload, n_local, peaks, pipelined, experiment=""):
     """HBM bytes per launch from the committed rocprofv3 PMC passes of this same command (profiles/*_pmc.json,
     written by tools/profile_bench.sh; FETCH_SIZE x2 + WRITE_SIZE), or None.  The newest
     matching record wins (files sort by round)."""
@@ -64,7 +64,7 @@ def pmc_traffic(kernel, workload, n_local, peaks, pipelined):
             rec = json.load(open(path))
         except (OSError, ValueError):
             continue
-        if rec.get("kernel") == kernel and rec.get("workload") == workload and rec.get("sources_per_gpu") == n_local and rec.get("peaks") == peaks and bool(rec.get("pipelined_mix", False)) == pipelined:
+        if rec.get("kernel") == kernel and rec.get("workload") == workload and rec.get("sources_per_gpu") == n_local and rec.get("peaks") == peaks and bool(rec.get("pipelined_mix", False)) == pipelined and rec.get("experiment", "") == experiment:
             best = (rec["traffic_bytes_per_launch"], os.path.basename(path))
     return best
 
@@ -342,6 +342,10 @@ def main():
             dist.init_process_group(backend, rank=rank, world_size=world)
 
     kind, chain, frames, n_default, ring, desc = WORKLOADS[args.workload]
+    if args.sources_per_gpu and args.sources_per_gpu != n_default:
+        desc += f" -- run with {args.sources_per_gpu} sources/GPU instead"
+    # anything that makes the run something other than the workload as described (PMC records only match like with like)
+    experiment = " ".join(f for f, on in (("--xcd-directions", args.xcd_directions), ("--xcd-order", args.xcd_order), ("--direction-order", args.direction_order), ("--presorted-directions", args.presorted_directions), ("--crossfade", args.crossfade)) if on)
     n_local = args.sources_per_gpu or n_default
     n_total = n_local * world
     begin, end = sharding.shard_range(n_total, rank, world)
@@ -413,6 +417,7 @@ def main():
                 "pipelined_mix": not args.no_pipelined_mix,
                 "host_enqueue_us_per_step": enq_ms / args.steps * 1e3,
                 "peaks": peaks_desc,
+                "experiment": experiment,
                 "parallelism": (f"source-sharded x{world} (world {world}, this rank on cuda:{local_rank}, {backend} reports {rccl_ranks} ranks), sum-reduce to rank 0 of {run.B} callbacks' partial mixes ({run.B * frames * 8} B) per collective on a side stream" + (" -- throughput arrangement: a callback's mix reaches rank 0 up to that many callbacks later; --reduce-bucket 1 is the real-time arrangement" if run.B > 1 else "")) if world > 1 else "single GPU (world 1, cuda:%d)" % local_rank,
                 "reduce_bucket": run.B,
                 "realtime_budget_ms": frames / 48000.0 * 1e3,
@@ -431,7 +436,7 @@ def main():
                 "algorithmic_bytes_per_launch": prof["bytes_per_launch"],
             },
         }
-        t = pmc_traffic(result["roofline"]["kernel"], desc, n_local, peaks_desc, not args.no_pipelined_mix)
+        t = pmc_traffic(result["roofline"]["kernel"], desc, n_local, peaks_desc, not args.no_pipelined_mix, experiment)
         if t:
             result["roofline"]["traffic"] = float(t[0])  # bytes per launch
             result["roofline"]["traffic_source"] = "profiles/" + t[1] + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command; FETCH x2 on gfx950)"

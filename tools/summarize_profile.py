@@ -47,6 +47,7 @@ def write_pmc_json(out, path):
         "sources_per_gpu": line["config"]["sources_per_gpu"],
         "peaks": line["config"].get("peaks"),
         "pipelined_mix": bool(line["config"].get("pipelined_mix", False)),
+        "experiment": line["config"].get("experiment", ""),
         "fetch_size_kib_raw": fetch,
         "write_size_kib_raw": write,
         "fetch_correction": 2.0,
