@@ -141,7 +141,11 @@ class Runner:
         self.env, self.gas, self.torch = env, gas, torch
         self.n_local, self.frames, self.flags = n_local, frames, flags
         self.pipelined = bool(flags & gas.capi.FLAG_PIPELINED_MIX)
+        self.paired = self.pipelined and bool(flags & gas.capi.FLAG_BATCHED_LAUNCH)
         self.ctx = gas.SpatializerContext(max_sources=n_local, frames=frames, channel_count=1, er_ring_frames=ring, device=env["local_rank"], flags=flags)
+        self.depth = max(1, min(8, args.batch_depth)) if self.paired else 1
+        if self.paired:
+            self.ctx.set_batch_depth(self.depth)
         self.ctx.set_stream(torch.cuda.current_stream().cuda_stream)
         if env["hrir"] is not None:
             self.ctx.hrtf_load(env["hrir"])
@@ -208,7 +212,11 @@ class Runner:
             raise SystemExit(f"gas_process_block failed: {rc}")
         if self.pipelined:
             # the last mix of the previous bucket rode in the launch above: that bucket is complete in stream order now
-            if i == 0 and k > 0:
+            # (batched launches: the first batch of this bucket carries the sums of the previous bucket's last batch)
+            aligned = self.depth > 1 and B % self.depth == 0
+            if i == (self.depth - 1 if aligned else 0) and k > i:
+                if self.depth > 1 and not aligned:
+                    ctx.join_outputs()  # buckets and batches do not line up: run what waits, sum what is pending
                 self.pending[1 - b] = self.reducer.reduce(self.buckets[1 - b])
         elif i == B - 1:
             self.pending[b] = self.reducer.reduce(self.buckets[b])
@@ -257,6 +265,7 @@ class Runner:
 
     def marked(self, callbacks):
         """Dominant-kernel time from HIP events recorded inside the library around every callback's main launch."""
+        callbacks = max(self.depth, callbacks // self.depth * self.depth)  # whole batches: every timed launch has the same size
         self.ctx.profile_enable(1)
         self.ctx.profile_read(reset=True)
         for k in range(callbacks):
@@ -304,10 +313,12 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-max-sources", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the ordered / exact-peaks / latency / copy-ceiling / max-sources passes (profiling runs)")
-    ap.add_argument("--marked-callbacks", type=int, default=48, help="callbacks of the separate pass that brackets the dominant launch with HIP events (0 = none: roofline fields empty)")
+    ap.add_argument("--marked-callbacks", type=int, default=96, help="callbacks of the separate pass that brackets the dominant launch with HIP events (0 = none: roofline fields empty)")
     ap.add_argument("--reduce-bucket", type=int, default=32, help="callbacks per cross-GPU reduce (N > 1); 1 = every callback's mix is reduced on its own (real-time arrangement)")
     ap.add_argument("--crossfade", action="store_true", help="GAS_FLAG_HRTF_CROSSFADE: blend old/new HRIRs when a source's direction changes (SURVEY 8f#4)")
     ap.add_argument("--no-pipelined-mix", action="store_true", help="headline without GAS_FLAG_PIPELINED_MIX: the partial-mix sum of callback t runs before callback t+1's DSP kernel instead of under it")
+    ap.add_argument("--no-paired-launch", action="store_true", help="throughput mode without GAS_FLAG_BATCHED_LAUNCH: one k_hrtf_uni launch per callback instead of one k_hrtf_multi launch per --batch-depth callbacks")
+    ap.add_argument("--batch-depth", type=int, default=8, help="GAS_FLAG_BATCHED_LAUNCH: callbacks per k_hrtf_multi launch (2 .. 8)")
     ap.add_argument("--direction-order", action="store_true", help="GAS_FLAG_DIRECTION_ORDER: let the library group sources by HRIR direction (device sort per publish)")
     ap.add_argument("--presorted-directions", action="store_true", help="GAS_FLAG_DIRECTION_RUNS with parameters whose HRIR directions are grouped in callback order (what a caller that sorts its list gets)")
     ap.add_argument("--xcd-order", action="store_true", help="GAS_FLAG_XCD_ORDER: XCD-affine processing order rebuilt on the device after every publish (experiment: fewer L2 fills, no net gain)")
@@ -345,7 +356,7 @@ def main():
     if args.sources_per_gpu and args.sources_per_gpu != n_default:
         desc += f" -- run with {args.sources_per_gpu} sources/GPU instead"
     # anything that makes the run something other than the workload as described (PMC records only match like with like)
-    experiment = " ".join(f for f, on in (("--xcd-directions", args.xcd_directions), ("--xcd-order", args.xcd_order), ("--direction-order", args.direction_order), ("--presorted-directions", args.presorted_directions), ("--crossfade", args.crossfade)) if on)
+    experiment = " ".join(f for f, on in (("--no-paired-launch", args.no_paired_launch and not args.no_pipelined_mix), ("--xcd-directions", args.xcd_directions), ("--xcd-order", args.xcd_order), ("--direction-order", args.direction_order), ("--presorted-directions", args.presorted_directions), ("--crossfade", args.crossfade)) if on)
     n_local = args.sources_per_gpu or n_default
     n_total = n_local * world
     begin, end = sharding.shard_range(n_total, rank, world)
@@ -367,7 +378,7 @@ def main():
         base_flags |= K.FLAG_DIRECTION_RUNS
     if args.xcd_order:
         base_flags |= K.FLAG_XCD_ORDER
-    head_flags = base_flags | (0 if args.no_pipelined_mix else K.FLAG_PIPELINED_MIX)
+    head_flags = base_flags | (0 if args.no_pipelined_mix else K.FLAG_PIPELINED_MIX | (0 if args.no_paired_launch else K.FLAG_BATCHED_LAUNCH))
 
     # ---- headline pass: exactly --steps callbacks, no markers inside -----------------------------------------------
     run = Runner(env, head_flags, n_local, args.reduce_bucket)
@@ -405,7 +416,7 @@ def main():
             "wall_ms_per_step": wall_ms / args.steps,
             "config": {
                 "workload": desc,
-                "mode": ("ordered (synchronous two-dispatch callback)" if args.no_pipelined_mix else "throughput: callbacks queued back to back, GAS_FLAG_PIPELINED_MIX (the sum of callback t's partial mixes rides in callback t+1's launch)") + ("" if args.exact_peaks else " + GAS_FLAG_PEAKS_DRAINING_ONLY"),
+                "mode": ("ordered (synchronous two-dispatch callback)" if args.no_pipelined_mix else "throughput: callbacks queued back to back, GAS_FLAG_PIPELINED_MIX (the sum of callback t's partial mixes rides in a later launch)" + ("" if args.no_paired_launch else f" + GAS_FLAG_BATCHED_LAUNCH ({args.batch_depth} consecutive callbacks per launch; outputs complete at gas_ctx_join_outputs)")) + ("" if args.exact_peaks else " + GAS_FLAG_PEAKS_DRAINING_ONLY"),
                 "timing": f"one HIP event pair on the launch stream around the {args.steps} callbacks (GPU timeline), {CONDITION_STEPS} untimed conditioning callbacks in front, max over ranks; wall_ms_per_step = host clock around the same region incl. the closing synchronize",
                 "parity": "unpinned: HRTF / early reflections have no reference counterpart, outputs are checked against this repository's oracle (DESIGN.md section 0)" if (3 in chain or 2 in chain) else "oracle restates audio_spatializer_3d.cpp:554-609; engine primitives unpinned (DESIGN.md section 0)",
                 "sources_total": n_total,
@@ -472,6 +483,13 @@ def main():
             lat = {"sources": n_local, **r2.latency(256)}
             r2.close()
             del r2
+            if head_flags & K.FLAG_BATCHED_LAUNCH:
+                r5 = Runner(env, head_flags & ~K.FLAG_BATCHED_LAUNCH, n_local, args.reduce_bucket)
+                g5, w5, _ = r5.timed(200, 20)
+                p5 = r5.marked(32)
+                result["unbatched"] = {"ms_per_step": g5 / 200, "value": n_local * frames * 200 / (g5 * 1e-3), "wall_ms_per_step": w5 / 200, "kernel_us": p5["kernel_ms"] / max(p5["launches"], 1) * 1e3, "kernel": p5["kernel"], "steps": 200, "what": "throughput mode without GAS_FLAG_BATCHED_LAUNCH: GAS_FLAG_PIPELINED_MIX only, one k_hrtf_uni launch per callback (round 1's headline arrangement)"}
+                r5.close()
+                del r5
             if kind == 2 and not args.exact_peaks:
                 r3 = Runner(env, 0, n_local, 1)
                 g3, w3, _ = r3.timed(200, 20)

@@ -28,6 +28,7 @@ FLAG_DIRECTION_ORDER = 4
 FLAG_PIPELINED_MIX = 8
 FLAG_DIRECTION_RUNS = 16
 FLAG_XCD_ORDER = 32
+FLAG_BATCHED_LAUNCH = 64
 
 STATUS = {
     0: "GAS_OK",
@@ -163,6 +164,7 @@ EXPORTS = [
     "gas_profile_enable",
     "gas_profile_read",
     "gas_bandwidth_probe",
+    "gas_ctx_set_batch_depth",
     "gas_ctx_read_hrtf_order",
 ]
 
@@ -238,6 +240,7 @@ def load_library():
     L.gas_profile_read.argtypes = [vp, C.POINTER(Profile), i32]
     L.gas_bandwidth_probe.argtypes = [vp, C.c_uint64, C.c_uint64, u32, u32, u32, C.POINTER(C.c_double)]
     L.gas_ctx_read_hrtf_order.argtypes = [vp, vp, u32]
+    L.gas_ctx_set_batch_depth.argtypes = [vp, u32]
     _lib = L
     return L
 
@@ -456,6 +459,10 @@ class SpatializerContext:
         us = C.c_double()
         self._check(self.lib.gas_bandwidth_probe(self.h, int(read_bytes), int(write_bytes), int(workgroups), int(unroll), int(iters), C.byref(us)), "gas_bandwidth_probe")
         return us.value
+
+    def set_batch_depth(self, depth):
+        """FLAG_BATCHED_LAUNCH: callbacks per k_hrtf_multi launch (1 .. 8)."""
+        self._check(self.lib.gas_ctx_set_batch_depth(self.h, int(depth)), "gas_ctx_set_batch_depth")
 
     def read_hrtf_order(self, n):
         """Diagnostic: the XCD-affine processing order of the last callback's plain [HRTF] sources."""

@@ -71,10 +71,25 @@ struct gas_ctx {
 	uint32_t pipe_tick = 0;
 	struct PendingMix {
 		bool valid = false;
-		int parity = 0;
+		int parity = 0; // plane of d_partials holding the callback's partial mixes
 		uint32_t p_total = 0;
 		gas_audio_frame *out = nullptr;
-	} pending_mix;
+	} pending_mix; // what a single launch carries / the first sum left by a batched launch
+	std::vector<PendingMix> pending_more; // the other sums a batched launch left (one per block)
+	// GAS_FLAG_BATCHED_LAUNCH: plain-[HRTF] device-memory callbacks wait here until batch_depth of them run as ONE
+	// k_hrtf_multi launch.  Anything that could change what the waiting callbacks must see runs them first.
+	struct Deferred {
+		const gas_audio_frame *src = nullptr;
+		gas_audio_frame *out = nullptr;
+		float *peaks = nullptr;
+		const gas_params *fresh = nullptr;
+	};
+	std::vector<Deferred> deferred;
+	uint32_t deferred_n = 0;
+	uint64_t deferred_groups_gen = 0;
+	uint32_t batch_depth = 2; // callbacks per launch (gas_ctx_set_batch_depth), <= GAS_HRTF_MULTI_MAX_BLOCKS
+	uint32_t partial_planes = 1; // planes of d_partials (1 ordered, 2 pipelined, 2 x max batch depth batched)
+	bool prof_multi = false; // the timed launch was k_hrtf_multi
 	uint32_t hist_len = 0;
 	gas_dev_state st{};
 	gas_hrtf_table tab{};
@@ -345,23 +360,58 @@ int ensure_partials(gas_ctx *c, uint32_t rows) {
 		c->d_partials = nullptr;
 		c->partial_rows = 0;
 	}
-	// two generations when the reduce is pipelined: callback t+1 fills one while callback t's is being summed
-	const size_t bytes = (size_t)(c->pipelined_mix ? 2 : 1) * rows * c->cfg.channel_count * c->cfg.frames * 2 * sizeof(float);
+	// two generations when the reduce is pipelined: callback t+1 fills one while callback t's is being summed; with
+	// batched launches one per block being filled and one per block being summed
+	c->partial_planes = c->pipelined_mix ? ((c->cfg.flags & GAS_FLAG_BATCHED_LAUNCH) != 0 ? 2u * GAS_HRTF_MULTI_MAX_BLOCKS : 2u) : 1u;
+	const size_t bytes = (size_t)c->partial_planes * rows * c->cfg.channel_count * c->cfg.frames * 2 * sizeof(float);
 	GAS_HIP(c, hipMalloc(&c->d_partials, bytes));
 	c->partial_rows = rows;
 	return GAS_OK;
 }
 
 // Launches the pending callback's k_mix_reduce on the context's stream (GAS_FLAG_PIPELINED_MIX).
+int reduce_now(gas_ctx *c, const gas_ctx::PendingMix &pm) {
+	const uint32_t F = c->cfg.frames;
+	const float *parts = c->d_partials + (size_t)pm.parity * c->partial_rows * c->cfg.channel_count * F * 2;
+	GAS_HIP(c, gas_launch_mix_reduce(c->stream, parts, pm.p_total, c->partial_rows, 1, F, pm.out));
+	return GAS_OK;
+}
+
 int join_outputs(gas_ctx *c) {
 	if (c->pending_mix.valid) {
 		const gas_ctx::PendingMix pm = c->pending_mix;
 		c->pending_mix.valid = false;
-		const uint32_t F = c->cfg.frames;
-		const float *parts = c->d_partials + (size_t)pm.parity * c->partial_rows * c->cfg.channel_count * F * 2;
-		GAS_HIP(c, gas_launch_mix_reduce(c->stream, parts, pm.p_total, c->partial_rows, 1, F, pm.out));
+		const int rc = reduce_now(c, pm);
+		if (rc != GAS_OK) {
+			return rc;
+		}
+	}
+	const std::vector<gas_ctx::PendingMix> more = std::move(c->pending_more);
+	c->pending_more.clear();
+	for (const gas_ctx::PendingMix &pm : more) {
+		const int rc = reduce_now(c, pm);
+		if (rc != GAS_OK) {
+			return rc;
+		}
 	}
 	return GAS_OK;
+}
+
+// A plane of d_partials that no pending sum still reads and that is not in `taken`.
+int free_plane(const gas_ctx *c, const std::vector<int> &taken) {
+	for (int p = 0; p < (int)c->partial_planes; p++) {
+		bool busy = c->pending_mix.valid && c->pending_mix.parity == p;
+		for (const gas_ctx::PendingMix &pm : c->pending_more) {
+			busy = busy || pm.parity == p;
+		}
+		for (int t : taken) {
+			busy = busy || t == p;
+		}
+		if (!busy) {
+			return p;
+		}
+	}
+	return -1;
 }
 
 // Device work of one callback over already-grouped entries.
@@ -386,6 +436,16 @@ int run_groups(gas_ctx *c, const gas_audio_frame *d_src, const uint32_t *d_slots
 	}
 	pipelined = pipelined && c->pipelined_mix && channel_count == 1 && c->cfg.channel_count == 1;
 	int rc = GAS_OK;
+	if (!c->pending_more.empty()) { // left by a batched launch: a single launch carries one sum only
+		const std::vector<gas_ctx::PendingMix> more = std::move(c->pending_more);
+		c->pending_more.clear();
+		for (const gas_ctx::PendingMix &pm : more) {
+			rc = reduce_now(c, pm);
+			if (rc != GAS_OK) {
+				return rc;
+			}
+		}
+	}
 	if (!pipelined || !carrier || (p_total > 0 ? p_total : 1) > c->partial_rows) {
 		rc = join_outputs(c); // nobody to carry the pending sum (or the partials are about to move): do it now
 		if (rc != GAS_OK) {
@@ -396,7 +456,7 @@ int run_groups(gas_ctx *c, const gas_audio_frame *d_src, const uint32_t *d_slots
 	if (rc != GAS_OK) {
 		return rc;
 	}
-	const int parity = pipelined ? (int)(c->pipe_tick & 1) : 0;
+	const int parity = pipelined ? free_plane(c, {}) : 0;
 	float *const parts = c->d_partials + (size_t)parity * c->partial_rows * c->cfg.channel_count * F * 2;
 	gas_deferred_reduce job; // handed to the first HRTF launch of this callback
 	if (c->pending_mix.valid) {
@@ -601,6 +661,7 @@ int run_groups(gas_ctx *c, const gas_audio_frame *d_src, const uint32_t *d_slots
 			}
 			c->prof_group = gt;
 			c->prof_uni = gt == G_FX_HRTF && uni_hrtf && groups[G_FX_HRTF_PK].count == 0;
+			c->prof_multi = false;
 			c->prof_pipe = (gt == G_3D_MIX || gt == G_3D_PROCESS || gt == G_FX_SHELF) && gas_biquad_uses_pipe(gt == G_FX_SHELF ? GAS_MODE_FX_HIGHSHELF : (force_mode >= 0 ? force_mode : (gt == G_3D_MIX ? GAS_MODE_MIX_CHANNEL : GAS_MODE_PROCESS_FRAMES)), gr.count, gt == G_3D_MIX ? channel_count : 1, F, false);
 		}
 		p_off += pcount[gt];
@@ -622,6 +683,150 @@ int run_groups(gas_ctx *c, const gas_audio_frame *d_src, const uint32_t *d_slots
 	if (channel_count > 1) {
 		GAS_HIP(c, gas_launch_mix_reduce(c->stream, parts + (size_t)c->partial_rows * F * 2, p_mix, c->partial_rows, channel_count - 1, F, d_out + F));
 	}
+	return GAS_OK;
+}
+
+int run_hrtf_batch(gas_ctx *c, const std::vector<gas_ctx::Deferred> &blocks, uint32_t n);
+
+// GAS_FLAG_BATCHED_LAUNCH: the waiting callbacks run now -- something is about to change what they must see, or somebody
+// wants their outputs.  The list, the groups and the parameter table are still the ones they were recorded with.
+int flush_deferred(gas_ctx *c) {
+	if (c->deferred.empty()) {
+		return GAS_OK;
+	}
+	const std::vector<gas_ctx::Deferred> blocks = std::move(c->deferred);
+	c->deferred.clear();
+	if (blocks.size() > 1) {
+		return run_hrtf_batch(c, blocks, c->deferred_n);
+	}
+	const gas_ctx::Deferred &d = blocks[0]; // a single one: k_hrtf_uni, exactly as the unbatched mode
+	c->fresh_for_launch = d.fresh;
+	const int rc = run_groups(c, d.src, c->d_slots, c->cached_identity_rows ? nullptr : c->d_rows, c->groups, c->chain_ranges, c->deferred_n, d.out, d.peaks, 0, c->cfg.channel_count, -1, true, true);
+	c->fresh_for_launch = nullptr;
+	return rc;
+}
+
+// Can this callback (already validated, groups built) wait for / run with its neighbours?
+bool batchable(const gas_ctx *c, uint32_t n) {
+	if ((c->cfg.flags & GAS_FLAG_BATCHED_LAUNCH) == 0 || c->batch_depth < 2 || !c->pipelined_mix || c->cfg.channel_count != 1 || !uni_ok(c) || c->fused_streams || (c->cfg.flags & GAS_FLAG_XCD_ORDER) != 0) {
+		return false;
+	}
+	for (int gt = 0; gt < G_COUNT; gt++) {
+		if (gt != G_FX_HRTF && c->groups[gt].count != 0) {
+			return false;
+		}
+	}
+	const uint32_t wgs = gas_hrtf_uni_partials(n);
+	// every wave of the launch has a source; every output column of a carried sum finds a job wave
+	return c->groups[G_FX_HRTF].count == n && n >= wgs * gas_hrtf_uni_waves() && wgs * GAS_HRTF_JOB_WAVES >= c->cfg.frames * 2 / 4 && wgs <= 256;
+}
+
+// 2 .. GAS_HRTF_MULTI_MAX_BLOCKS consecutive callbacks of the current list in ONE k_hrtf_multi launch.
+int run_hrtf_batch(gas_ctx *c, const std::vector<gas_ctx::Deferred> &blocks, uint32_t n) {
+	const uint32_t F = c->cfg.frames, K = (uint32_t)blocks.size();
+	const uint32_t wgs = gas_hrtf_uni_partials(n);
+	int rc = GAS_OK;
+	bool tall = c->pending_mix.valid && c->pending_mix.p_total > 256;
+	for (const gas_ctx::PendingMix &pm : c->pending_more) {
+		tall = tall || pm.p_total > 256;
+	}
+	if (wgs > c->partial_rows || c->partial_planes < 2 * GAS_HRTF_MULTI_MAX_BLOCKS || tall) {
+		rc = join_outputs(c); // the partials are about to move, or a pending sum is too tall for a job wave
+		if (rc != GAS_OK) {
+			return rc;
+		}
+	}
+	rc = ensure_partials(c, wgs);
+	if (rc != GAS_OK) {
+		return rc;
+	}
+	const Group &gr = c->groups[G_FX_HRTF];
+	gas_group_args ga;
+	ga.src = blocks[0].src;
+	ga.rows = c->cached_identity_rows ? nullptr : c->d_rows + gr.offset;
+	ga.slots = c->d_slots + gr.offset;
+	ga.slot_base = 0;
+	ga.n = n;
+	ga.peaks = blocks[0].peaks;
+	if (gr.contiguous) {
+		ga.slots = nullptr;
+		ga.slot_base = gr.slot_base;
+	}
+	gas_hrtf_blocks mb;
+	mb.k = K;
+	for (uint32_t b = 0; b < K; b++) {
+		mb.src[b] = blocks[b].src;
+		mb.fresh[b] = blocks[b].fresh;
+		mb.peaks[b] = blocks[b].peaks;
+		if (blocks[b].fresh) {
+			mb.last_fresh = blocks[b].fresh;
+		}
+	}
+	// the pending sums ride with the first blocks of this launch, one each; any beyond that are summed right away
+	const size_t plane_elems = (size_t)c->partial_rows * c->cfg.channel_count * F * 2;
+	std::vector<gas_ctx::PendingMix> carried;
+	if (c->pending_mix.valid) {
+		carried.push_back(c->pending_mix);
+	}
+	for (const gas_ctx::PendingMix &pm : c->pending_more) {
+		carried.push_back(pm);
+	}
+	uint64_t carried_bytes = 0;
+	for (size_t j = 0; j < carried.size(); j++) {
+		if (j < K) {
+			gas_deferred_reduce &job = mb.job[j];
+			job.partials = c->d_partials + (size_t)carried[j].parity * plane_elems;
+			job.p_count = carried[j].p_total;
+			job.elems = F * 2;
+			job.out = reinterpret_cast<float *>(carried[j].out);
+			carried_bytes += ((uint64_t)job.p_count + 1) * job.elems * sizeof(float);
+		} else {
+			rc = reduce_now(c, carried[j]);
+			if (rc != GAS_OK) {
+				return rc;
+			}
+		}
+	}
+	// the planes this launch fills: none that a carried sum still reads (the pending records stay in place until the
+	// planes are chosen)
+	std::vector<int> planes;
+	for (uint32_t b = 0; b < K; b++) {
+		const int pl = free_plane(c, planes);
+		if (pl < 0) {
+			return GAS_ERR_DEVICE; // cannot happen: <= MAX carried + MAX filled of 2 MAX planes
+		}
+		planes.push_back(pl);
+		mb.p_offset[b] = (uint32_t)pl * c->partial_rows * c->cfg.channel_count;
+	}
+	c->pending_mix.valid = false;
+	c->pending_more.clear();
+	const bool timed = c->profiling && c->ev_used + 2 <= c->ev.size() && (c->prof_tick++ % c->prof_every) == 0;
+	if (timed) {
+		GAS_HIP(c, hipEventRecord(c->ev[c->ev_used], c->stream));
+	}
+	GAS_HIP(c, gas_launch_hrtf_multi(c->stream, ga, mb, c->uni_peak_any && !c->uni_peak_all ? c->d_peak_bits : nullptr, c->uni_peak_all, c->st, c->tab, c->d_tw, F, c->hist_len, c->d_partials));
+	if (timed) {
+		GAS_HIP(c, hipEventRecord(c->ev[c->ev_used + 1], c->stream));
+		c->ev_used += 2;
+		c->prof_bytes = (uint64_t)K * group_bytes(c, G_FX_HRTF, n) + carried_bytes;
+		c->prof_group = G_FX_HRTF;
+		c->prof_uni = false;
+		c->prof_pipe = false;
+		c->prof_multi = true;
+	}
+	for (uint32_t b = 0; b < K; b++) {
+		gas_ctx::PendingMix pm;
+		pm.valid = true;
+		pm.parity = planes[b];
+		pm.p_total = wgs;
+		pm.out = blocks[b].out;
+		if (b == 0) {
+			c->pending_mix = pm;
+		} else {
+			c->pending_more.push_back(pm);
+		}
+	}
+	c->pipe_tick += K;
 	return GAS_OK;
 }
 
@@ -863,6 +1068,7 @@ void gas_ctx_destroy(gas_ctx *c) {
 		return;
 	}
 	(void)hipSetDevice(c->cfg.device);
+	c->deferred.clear(); // callbacks still waiting for their batch are dropped with the context
 	if (c->stream) {
 		(void)hipStreamSynchronize(c->stream);
 	}
@@ -1043,6 +1249,12 @@ int gas_ctx_set_stream(gas_ctx *c, void *hip_stream) {
 	if (!c) {
 		return GAS_ERR_INVALID_ARGUMENT;
 	}
+	{ // GAS_FLAG_BATCHED_LAUNCH: callbacks waiting for their batch run first
+		const int rcd = flush_deferred(c);
+		if (rcd != GAS_OK) {
+			return rcd;
+		}
+	}
 	GAS_HIP(c, hipSetDevice(c->cfg.device));
 	{
 		int rcj = join_outputs(c);
@@ -1071,6 +1283,12 @@ int gas_ctx_synchronize(gas_ctx *c) {
 	if (!c) {
 		return GAS_ERR_INVALID_ARGUMENT;
 	}
+	{ // GAS_FLAG_BATCHED_LAUNCH: callbacks waiting for their batch run first
+		const int rcd = flush_deferred(c);
+		if (rcd != GAS_OK) {
+			return rcd;
+		}
+	}
 	GAS_HIP(c, hipSetDevice(c->cfg.device));
 	{
 		int rcj = join_outputs(c);
@@ -1082,9 +1300,29 @@ int gas_ctx_synchronize(gas_ctx *c) {
 	return GAS_OK;
 }
 
+int gas_ctx_set_batch_depth(gas_ctx *c, uint32_t depth) {
+	if (!c || depth < 1 || depth > GAS_HRTF_MULTI_MAX_BLOCKS) {
+		return GAS_ERR_INVALID_ARGUMENT;
+	}
+	{ // callbacks waiting for the old depth run first
+		const int rcd = flush_deferred(c);
+		if (rcd != GAS_OK) {
+			return rcd;
+		}
+	}
+	c->batch_depth = depth;
+	return GAS_OK;
+}
+
 int gas_ctx_join_outputs(gas_ctx *c) {
 	if (!c) {
 		return GAS_ERR_INVALID_ARGUMENT;
+	}
+	{ // GAS_FLAG_BATCHED_LAUNCH: callbacks waiting for their batch run first
+		const int rcd = flush_deferred(c);
+		if (rcd != GAS_OK) {
+			return rcd;
+		}
 	}
 	GAS_HIP(c, hipSetDevice(c->cfg.device));
 	return join_outputs(c);
@@ -1155,6 +1393,12 @@ int gas_source_reset(gas_ctx *c, uint32_t slot) {
 	if (!c) {
 		return GAS_ERR_INVALID_ARGUMENT;
 	}
+	{ // GAS_FLAG_BATCHED_LAUNCH: callbacks waiting for their batch run first
+		const int rcd = flush_deferred(c);
+		if (rcd != GAS_OK) {
+			return rcd;
+		}
+	}
 	if (slot >= c->cfg.max_sources || !c->slots[slot].used) {
 		return GAS_ERR_BAD_SLOT;
 	}
@@ -1214,6 +1458,12 @@ int gas_params_publish_batch(gas_ctx *c, const uint32_t *slots, const gas_params
 	// slots == NULL addresses the slot list of the last gas_process_block, in its row order.
 	GAS_HIP(c, hipSetDevice(c->cfg.device));
 	if (slots) {
+		{ // GAS_FLAG_BATCHED_LAUNCH: callbacks waiting for their batch run first
+			const int rcd = flush_deferred(c);
+			if (rcd != GAS_OK) {
+				return rcd;
+			}
+		}
 		int rcp = flush_pending_params(c);
 		if (rcp != GAS_OK) {
 			return rcp;
@@ -1257,6 +1507,12 @@ int gas_calc_spatialization_areas(gas_ctx *c, const gas_spatializer3d_config *cf
 	}
 	if (n_cfgs == 0 || n_cfgs > GAS_MAX_SPATIALIZER_CONFIGS || n_listeners > GAS_MAX_LISTENERS || n > c->cfg.max_sources) {
 		return GAS_ERR_INVALID_ARGUMENT;
+	}
+	{ // GAS_FLAG_BATCHED_LAUNCH: callbacks waiting for their batch run first
+		const int rcd = flush_deferred(c);
+		if (rcd != GAS_OK) {
+			return rcd;
+		}
 	}
 	for (uint32_t i = 0; i < n_cfgs; i++) {
 		if (cfgs[i].speaker_mode < 0 || cfgs[i].speaker_mode > 3 || !(cfgs[i].unit_size > 0.0f)) {
@@ -1464,6 +1720,12 @@ int gas_process_block_streams(gas_ctx *c, const uint32_t *slots, uint32_t n, uin
 	if (!c || !out || (n > 0 && !slots) || n > c->cfg.max_sources || (mem != GAS_MEM_HOST && mem != GAS_MEM_DEVICE)) {
 		return GAS_ERR_INVALID_ARGUMENT;
 	}
+	{ // GAS_FLAG_BATCHED_LAUNCH: callbacks waiting for their batch run first
+		const int rcd = flush_deferred(c);
+		if (rcd != GAS_OK) {
+			return rcd;
+		}
+	}
 	const uint32_t F = c->cfg.frames, C = c->cfg.channel_count;
 	auto fail = [&](int code) {
 		if (mem == GAS_MEM_HOST) {
@@ -1657,6 +1919,12 @@ int gas_hrtf_load(gas_ctx *c, const float *hrir, uint32_t dirs, uint32_t taps) {
 	if (!c || !hrir || dirs == 0 || taps == 0 || taps > GAS_HRTF_TAPS) {
 		return GAS_ERR_INVALID_ARGUMENT;
 	}
+	{ // GAS_FLAG_BATCHED_LAUNCH: callbacks waiting for their batch run first
+		const int rcd = flush_deferred(c);
+		if (rcd != GAS_OK) {
+			return rcd;
+		}
+	}
 	GAS_HIP(c, hipSetDevice(c->cfg.device));
 	GAS_HIP(c, hipStreamSynchronize(c->stream));
 	if (c->tab.spec) {
@@ -1700,6 +1968,20 @@ int gas_process_block(gas_ctx *c, const gas_audio_frame *src, const uint32_t *sl
 	}
 	if (hipSetDevice(c->cfg.device) != hipSuccess) {
 		return fail(GAS_ERR_NO_DEVICE);
+	}
+	if (!c->deferred.empty()) { // GAS_FLAG_BATCHED_LAUNCH: do the waiting callbacks still see what they were recorded with?
+		bool host_dirty = false;
+		{
+			std::lock_guard<std::mutex> lk(c->params_mu);
+			host_dirty = !c->dirty_list.empty();
+		}
+		const bool keep = mem == GAS_MEM_DEVICE && !slots && n == c->deferred_n && c->pending_free.empty() && c->groups_gen == c->deferred_groups_gen && !host_dirty;
+		if (!keep) {
+			rc = flush_deferred(c);
+			if (rc != GAS_OK) {
+				return fail(rc);
+			}
+		}
 	}
 	if (c->pending_params && (slots || n == 0 || c->cached_n != n || !c->pending_free.empty())) {
 		rc = flush_pending_params(c); // the list may change: scatter with the mapping it was published for
@@ -1773,6 +2055,32 @@ int gas_process_block(gas_ctx *c, const gas_audio_frame *src, const uint32_t *sl
 			}
 		}
 	}
+	if (mem == GAS_MEM_DEVICE && batchable(c, n)) {
+		gas_ctx::Deferred cur;
+		cur.src = d_src;
+		cur.out = d_out;
+		cur.peaks = d_peaks;
+		cur.fresh = c->fresh_for_launch;
+		c->fresh_for_launch = nullptr;
+		c->deferred.push_back(cur); // nothing is enqueued yet: this callback runs with its neighbours (or when flushed)
+		c->deferred_n = n;
+		c->deferred_groups_gen = c->groups_gen;
+		const uint32_t depth = c->batch_depth < GAS_HRTF_MULTI_MAX_BLOCKS ? c->batch_depth : GAS_HRTF_MULTI_MAX_BLOCKS;
+		if (c->deferred.size() >= depth) {
+			rc = flush_deferred(c);
+			return rc == GAS_OK ? GAS_OK : fail(rc);
+		}
+		return GAS_OK;
+	}
+	if (!c->deferred.empty()) {
+		const gas_params *fresh = c->fresh_for_launch;
+		rc = flush_deferred(c);
+		if (rc != GAS_OK) {
+			c->fresh_for_launch = nullptr;
+			return fail(rc);
+		}
+		c->fresh_for_launch = fresh;
+	}
 	rc = run_groups(c, d_src, c->d_slots, c->cached_identity_rows ? nullptr : c->d_rows, c->groups, c->chain_ranges, n, d_out, d_peaks, 0, C, -1, true, mem == GAS_MEM_DEVICE);
 	c->fresh_for_launch = nullptr;
 	if (rc != GAS_OK) {
@@ -1816,6 +2124,12 @@ int gas_bus_routes_publish(gas_ctx *c, const uint32_t *slots, const gas_bus_rout
 int gas_process_block_buses(gas_ctx *c, const gas_audio_frame *src, const uint32_t *slots, uint32_t n, uint32_t frames, gas_audio_frame *out, uint32_t n_buses, float *peaks, int mem) {
 	if (!c || !out || (mem != GAS_MEM_HOST && mem != GAS_MEM_DEVICE) || (n > 0 && (!src || !slots)) || n > c->cfg.max_sources || n_buses < 1 || n_buses > GAS_MAX_BUSES) {
 		return GAS_ERR_INVALID_ARGUMENT;
+	}
+	{ // GAS_FLAG_BATCHED_LAUNCH: callbacks waiting for their batch run first
+		const int rcd = flush_deferred(c);
+		if (rcd != GAS_OK) {
+			return rcd;
+		}
 	}
 	const uint32_t F = c->cfg.frames, C = c->cfg.channel_count;
 	const size_t out_bytes = (size_t)n_buses * C * F * sizeof(gas_audio_frame);
@@ -1937,6 +2251,12 @@ static int process_one(gas_ctx *c, uint32_t slot, int channel, bool mix_channel,
 	if (!c || !out || !src) {
 		return GAS_ERR_INVALID_ARGUMENT;
 	}
+	{ // GAS_FLAG_BATCHED_LAUNCH: callbacks waiting for their batch run first
+		const int rcd = flush_deferred(c);
+		if (rcd != GAS_OK) {
+			return rcd;
+		}
+	}
 	const uint32_t F = c->cfg.frames;
 	if (frame_count < 0 || (uint32_t)frame_count != F) {
 		return GAS_ERR_FRAME_COUNT;
@@ -2024,6 +2344,12 @@ int gas_profile_enable(gas_ctx *c, int on) {
 	if (!c) {
 		return GAS_ERR_INVALID_ARGUMENT;
 	}
+	{ // GAS_FLAG_BATCHED_LAUNCH: callbacks waiting for their batch run first
+		const int rcd = flush_deferred(c);
+		if (rcd != GAS_OK) {
+			return rcd;
+		}
+	}
 	GAS_HIP(c, hipSetDevice(c->cfg.device));
 	if (on && c->ev.empty()) {
 		c->ev.resize(PROFILE_EVENTS);
@@ -2058,6 +2384,12 @@ int gas_ctx_read_hrtf_order(gas_ctx *c, uint32_t *out, uint32_t n) {
 	if (!c || !out) {
 		return GAS_ERR_INVALID_ARGUMENT;
 	}
+	{ // GAS_FLAG_BATCHED_LAUNCH: callbacks waiting for their batch run first
+		const int rcd = flush_deferred(c);
+		if (rcd != GAS_OK) {
+			return rcd;
+		}
+	}
 	if (!c->d_order || !c->order_ok[G_FX_HRTF] || !c->last_uni_ordered || n > c->groups[G_FX_HRTF].count) {
 		return GAS_ERR_INVALID_ARGUMENT;
 	}
@@ -2070,6 +2402,12 @@ int gas_ctx_read_hrtf_order(gas_ctx *c, uint32_t *out, uint32_t n) {
 int gas_bandwidth_probe(gas_ctx *c, uint64_t read_bytes, uint64_t write_bytes, uint32_t workgroups, uint32_t unroll, uint32_t iters, double *out_us) {
 	if (!c || !out_us || iters == 0 || workgroups == 0 || read_bytes % 16 != 0 || write_bytes % 16 != 0 || read_bytes + write_bytes == 0) {
 		return GAS_ERR_INVALID_ARGUMENT;
+	}
+	{ // GAS_FLAG_BATCHED_LAUNCH: callbacks waiting for their batch run first
+		const int rcd = flush_deferred(c);
+		if (rcd != GAS_OK) {
+			return rcd;
+		}
 	}
 	GAS_HIP(c, hipSetDevice(c->cfg.device));
 	GAS_HIP(c, hipStreamSynchronize(c->stream));
@@ -2144,6 +2482,12 @@ int gas_profile_read(gas_ctx *c, gas_profile *out, int reset) {
 	if (!c || !out) {
 		return GAS_ERR_INVALID_ARGUMENT;
 	}
+	{ // GAS_FLAG_BATCHED_LAUNCH: callbacks waiting for their batch run first
+		const int rcd = flush_deferred(c);
+		if (rcd != GAS_OK) {
+			return rcd;
+		}
+	}
 	GAS_HIP(c, hipSetDevice(c->cfg.device));
 	GAS_HIP(c, hipStreamSynchronize(c->stream));
 	for (uint32_t i = 0; i + 1 < c->ev_used; i += 2) {
@@ -2158,7 +2502,7 @@ int gas_profile_read(gas_ctx *c, gas_profile *out, int reset) {
 	out->kernel_ms = c->prof_ms;
 	out->bytes_per_launch = c->prof_bytes;
 	if (c->prof_group >= 0) {
-		std::string name = c->prof_uni ? "k_hrtf_uni" : k_group_kernel[c->prof_group];
+		std::string name = c->prof_multi ? "k_hrtf_multi" : (c->prof_uni ? "k_hrtf_uni" : k_group_kernel[c->prof_group]);
 		if (c->prof_pipe && name.rfind("k_biquad_mix", 0) == 0) {
 			name = "k_biquad_pipe" + name.substr(12);
 		}

@@ -132,6 +132,21 @@ typedef struct gas_config {
  * kept because it answers what the excess traffic costs.  The mix is the same sum in another (still deterministic)
  * order: results agree to f32 rounding, not bitwise, with the unordered launch. */
 #define GAS_FLAG_XCD_ORDER 32u
+/* With GAS_FLAG_PIPELINED_MIX, for callers that queue callbacks faster than they consume them (offline rendering,
+ * benchmarks): consecutive gas_process_block(GAS_MEM_DEVICE) calls of an unchanged plain-[HRTF] list run as ONE launch
+ * per `depth` callbacks (k_hrtf_multi: no dispatch gap between them, a callback's epilogue under the next one's
+ * stream; depth 2 unless gas_ctx_set_batch_depth says otherwise).  A call only records its arguments until the batch is
+ * full; the call that fills it enqueues all of them.  Same operations in the same order: results are bitwise those of
+ * the unbatched mode.  What changes for the caller:
+ *  - `src`, `peaks` and device-published parameter rows of a call must stay valid and unmodified until `depth - 1`
+ *    further gas_process_block calls on this context (or gas_ctx_join_outputs / gas_ctx_synchronize) have returned;
+ *  - `out` is complete only after gas_ctx_join_outputs / gas_ctx_synchronize (or any ordered call), in stream order;
+ *  - every entry of the context must be called from ONE thread (the recorded calls are run by whoever comes next:
+ *    anything that changes what they must see -- a new list, host-published parameters, frees, any other entry that
+ *    enqueues work -- first runs them, exactly as the unbatched mode would have);
+ *  - callbacks that do not qualify (other source kinds, < 2048 sources, 2 or more channel pairs, streams, cross-fade
+ *    or direction flags) run as before. */
+#define GAS_FLAG_BATCHED_LAUNCH 64u
 
 /* SpatializerParameters (spatializer_parameters.h:39-67) + SpatializerParameters3D
  * (audio_spatializer_3d.h:61-83) as one 128-byte POD, plus the per-block effect
@@ -167,6 +182,8 @@ void gas_ctx_destroy(gas_ctx *ctx);
 /* Run on an existing HIP stream (hipStream_t) instead of the context's own. */
 int gas_ctx_set_stream(gas_ctx *ctx, void *hip_stream);
 int gas_ctx_synchronize(gas_ctx *ctx);
+/* GAS_FLAG_BATCHED_LAUNCH: callbacks per launch, 1 (off) .. 8; takes effect with the next batch. */
+int gas_ctx_set_batch_depth(gas_ctx *ctx, uint32_t depth);
 /* GAS_FLAG_PIPELINED_MIX: enqueue the deferred sum of the last gas_process_block, so that work enqueued on the
  * context's stream after this call sees its `out`.  Non-blocking; no-op when nothing is pending. */
 int gas_ctx_join_outputs(gas_ctx *ctx);
