@@ -142,8 +142,8 @@ class Runner:
         self.n_local, self.frames, self.flags = n_local, frames, flags
         self.pipelined = bool(flags & gas.capi.FLAG_PIPELINED_MIX)
         self.paired = self.pipelined and bool(flags & gas.capi.FLAG_BATCHED_LAUNCH)
+        self.depth = max(1, min(16, args.batch_depth)) if self.paired else 1
         self.ctx = gas.SpatializerContext(max_sources=n_local, frames=frames, channel_count=1, er_ring_frames=ring, device=env["local_rank"], flags=flags)
-        self.depth = max(1, min(8, args.batch_depth)) if self.paired else 1
         if self.paired:
             self.ctx.set_batch_depth(self.depth)
         self.ctx.set_stream(torch.cuda.current_stream().cuda_stream)
@@ -182,6 +182,8 @@ class Runner:
         # collective (B x 4 KiB) on a side stream while the next bucket is being computed: the 4 KiB per-callback
         # message is latency-bound over xGMI.  That is a THROUGHPUT arrangement (callbacks queued back to back, the
         # mix of a callback reaches rank 0 up to B callbacks later); a real-time host uses --reduce-bucket 1.
+        if self.depth > 1 and bucket >= self.depth:
+            bucket = bucket // self.depth * self.depth  # whole batches per bucket: the carried sums line up with the reduces
         self.B = B = max(1, bucket)
         self.buckets = [torch.zeros(B, 1, frames, 2, device="cuda") for _ in range(2)]
         self.peaks = torch.zeros(n_local, 2, device="cuda")
@@ -215,7 +217,7 @@ class Runner:
             # (batched launches: the first batch of this bucket carries the sums of the previous bucket's last batch)
             aligned = self.depth > 1 and B % self.depth == 0
             if i == (self.depth - 1 if aligned else 0) and k > i:
-                if self.depth > 1 and not aligned:
+                if self.depth > 1 and not aligned and self.env["world"] > 1:
                     ctx.join_outputs()  # buckets and batches do not line up: run what waits, sum what is pending
                 self.pending[1 - b] = self.reducer.reduce(self.buckets[1 - b])
         elif i == B - 1:
@@ -313,12 +315,12 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-max-sources", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the ordered / exact-peaks / latency / copy-ceiling / max-sources passes (profiling runs)")
-    ap.add_argument("--marked-callbacks", type=int, default=96, help="callbacks of the separate pass that brackets the dominant launch with HIP events (0 = none: roofline fields empty)")
+    ap.add_argument("--marked-callbacks", type=int, default=320, help="callbacks of the separate pass that brackets the dominant launch with HIP events (0 = none: roofline fields empty)")
     ap.add_argument("--reduce-bucket", type=int, default=32, help="callbacks per cross-GPU reduce (N > 1); 1 = every callback's mix is reduced on its own (real-time arrangement)")
     ap.add_argument("--crossfade", action="store_true", help="GAS_FLAG_HRTF_CROSSFADE: blend old/new HRIRs when a source's direction changes (SURVEY 8f#4)")
     ap.add_argument("--no-pipelined-mix", action="store_true", help="headline without GAS_FLAG_PIPELINED_MIX: the partial-mix sum of callback t runs before callback t+1's DSP kernel instead of under it")
     ap.add_argument("--no-paired-launch", action="store_true", help="throughput mode without GAS_FLAG_BATCHED_LAUNCH: one k_hrtf_uni launch per callback instead of one k_hrtf_multi launch per --batch-depth callbacks")
-    ap.add_argument("--batch-depth", type=int, default=8, help="GAS_FLAG_BATCHED_LAUNCH: callbacks per k_hrtf_multi launch (2 .. 8)")
+    ap.add_argument("--batch-depth", type=int, default=10, help="GAS_FLAG_BATCHED_LAUNCH: callbacks per k_hrtf_multi launch (2 .. 16)")
     ap.add_argument("--direction-order", action="store_true", help="GAS_FLAG_DIRECTION_ORDER: let the library group sources by HRIR direction (device sort per publish)")
     ap.add_argument("--presorted-directions", action="store_true", help="GAS_FLAG_DIRECTION_RUNS with parameters whose HRIR directions are grouped in callback order (what a caller that sorts its list gets)")
     ap.add_argument("--xcd-order", action="store_true", help="GAS_FLAG_XCD_ORDER: XCD-affine processing order rebuilt on the device after every publish (experiment: fewer L2 fills, no net gain)")

@@ -461,7 +461,7 @@ class SpatializerContext:
         return us.value
 
     def set_batch_depth(self, depth):
-        """FLAG_BATCHED_LAUNCH: callbacks per k_hrtf_multi launch (1 .. 8)."""
+        """FLAG_BATCHED_LAUNCH: callbacks per k_hrtf_multi launch (1 .. 16)."""
         self._check(self.lib.gas_ctx_set_batch_depth(self.h, int(depth)), "gas_ctx_set_batch_depth")
 
     def read_hrtf_order(self, n):

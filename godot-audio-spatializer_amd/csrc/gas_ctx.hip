@@ -378,21 +378,30 @@ int reduce_now(gas_ctx *c, const gas_ctx::PendingMix &pm) {
 }
 
 int join_outputs(gas_ctx *c) {
+	std::vector<gas_ctx::PendingMix> all;
 	if (c->pending_mix.valid) {
-		const gas_ctx::PendingMix pm = c->pending_mix;
+		all.push_back(c->pending_mix);
 		c->pending_mix.valid = false;
-		const int rc = reduce_now(c, pm);
-		if (rc != GAS_OK) {
-			return rc;
-		}
 	}
-	const std::vector<gas_ctx::PendingMix> more = std::move(c->pending_more);
+	for (const gas_ctx::PendingMix &pm : c->pending_more) {
+		all.push_back(pm);
+	}
 	c->pending_more.clear();
-	for (const gas_ctx::PendingMix &pm : more) {
-		const int rc = reduce_now(c, pm);
-		if (rc != GAS_OK) {
-			return rc;
+	if (all.size() == 1) {
+		return reduce_now(c, all[0]);
+	}
+	// the sums a batched launch left: one launch for all of them (eight k_mix_reduce launches cost 38 us)
+	const uint32_t F = c->cfg.frames;
+	const size_t plane_elems = (size_t)c->partial_rows * c->cfg.channel_count * F * 2;
+	for (size_t i = 0; i < all.size(); i += GAS_HRTF_MULTI_MAX_BLOCKS) {
+		gas_reduce_jobs jobs;
+		for (size_t j = i; j < all.size() && j < i + GAS_HRTF_MULTI_MAX_BLOCKS; j++) {
+			jobs.partials[jobs.count] = c->d_partials + (size_t)all[j].parity * plane_elems;
+			jobs.p_count[jobs.count] = all[j].p_total;
+			jobs.out[jobs.count] = reinterpret_cast<float *>(all[j].out);
+			jobs.count++;
 		}
+		GAS_HIP(c, gas_launch_mix_reduce_jobs(c->stream, jobs, F));
 	}
 	return GAS_OK;
 }

@@ -30,6 +30,18 @@ __device__ __forceinline__ float2 cmul(float2 a, float2 b) {
 __device__ __forceinline__ float2 cmulc(float2 a, float2 b) { // a * conj(b)
 	return make_float2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y);
 }
+// acc += z * h and y = z * h with the roundings spelled out (explicit fused multiply-adds, no compiler contraction):
+// k_hrtf_uni and k_hrtf_multi must produce the same bits from the same inputs (tests/test_gpu_batched.py), which they
+// only do when neither leaves the choice of what to fuse to the optimiser.
+__device__ __forceinline__ void cmac_fixed(float2 &acc, float2 z, float hx, float hy) {
+#pragma clang fp contract(off)
+	acc.x = __builtin_fmaf(z.x, hx, __builtin_fmaf(-z.y, hy, acc.x));
+	acc.y = __builtin_fmaf(z.x, hy, __builtin_fmaf(z.y, hx, acc.y));
+}
+__device__ __forceinline__ float2 cmul_fixed(float2 z, float hx, float hy) {
+#pragma clang fp contract(off)
+	return make_float2(__builtin_fmaf(z.x, hx, -(z.y * hy)), __builtin_fmaf(z.x, hy, z.y * hx));
+}
 // Once-touched streams (source rows, history) bypass the caches' retention so they do not evict the HRIR
 // spectra table, which is the only data re-read across sources (MI355X_MICROARCH.md nt-weights row).
 #ifndef GAS_ABL

@@ -112,7 +112,7 @@ hipError_t gas_launch_hrtf_ols(hipStream_t stream, bool with_er, bool crossfade,
 uint32_t gas_hrtf_uni_partials(uint32_t n); // workgroups (= partial mixes) of a k_hrtf_uni launch
 
 // k_hrtf_multi.hip: K consecutive callbacks of one unchanged plain-[HRTF] list in one launch (GAS_FLAG_PIPELINED_MIX)
-#define GAS_HRTF_MULTI_MAX_BLOCKS 8
+#define GAS_HRTF_MULTI_MAX_BLOCKS 16
 struct gas_hrtf_blocks {
 	uint32_t k = 0; // blocks in this launch
 	const gas_audio_frame *src[GAS_HRTF_MULTI_MAX_BLOCKS] = {}; // [n][F] rows of block b
@@ -122,6 +122,14 @@ struct gas_hrtf_blocks {
 	gas_deferred_reduce job[GAS_HRTF_MULTI_MAX_BLOCKS]; // pending sums of EARLIER launches carried by block b's idle waves
 	const gas_params *last_fresh = nullptr; // the last non-null fresh[]: written through to the slot table at the end
 };
+// several independent deterministic sums (k_mix_reduce's) in one launch
+struct gas_reduce_jobs {
+	uint32_t count = 0;
+	const float *partials[GAS_HRTF_MULTI_MAX_BLOCKS] = {}; // [p_count][F * 2] each
+	uint32_t p_count[GAS_HRTF_MULTI_MAX_BLOCKS] = {};
+	float *out[GAS_HRTF_MULTI_MAX_BLOCKS] = {};
+};
+hipError_t gas_launch_mix_reduce_jobs(hipStream_t stream, const gas_reduce_jobs &jobs, uint32_t frames);
 hipError_t gas_launch_hrtf_multi(hipStream_t stream, const gas_group_args &g, const gas_hrtf_blocks &mb, const uint32_t *peak_bits, bool peak_all, const gas_dev_state &st, const gas_hrtf_table &tab, const float2 *twiddles, uint32_t frames, uint32_t hist_len, float *partials);
 hipError_t gas_launch_hrtf_uni(hipStream_t stream, const gas_group_args &g, const uint32_t *peak_bits, bool peak_all, const gas_dev_state &st, const gas_hrtf_table &tab, const float2 *twiddles, uint32_t frames, uint32_t hist_len, float *partials, uint32_t p_offset, gas_cursor *cursors, const float *fade_env, const gas_params *fresh, const gas_deferred_reduce &job = gas_deferred_reduce());
 hipError_t gas_launch_er_only(hipStream_t stream, const gas_group_args &g, const gas_dev_state &st, uint32_t frames, uint32_t er_ring_frames, float *partials, uint32_t p_offset, uint32_t p_stride, gas_audio_frame *rows_out = nullptr);

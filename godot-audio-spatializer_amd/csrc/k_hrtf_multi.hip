@@ -26,9 +26,13 @@ constexpr int MAXB = GAS_HRTF_MULTI_MAX_BLOCKS;
 
 template <int SQ>
 struct MultiLds {
-	static constexpr int SLICES_F2 = MW * 2 * LDS_F2_HALF; // two exchange slices per wave
+	static constexpr int SLICES_F2 = MW * LDS_F2_HALF; // one exchange slice per wave (no transform pair in this kernel)
 	static constexpr int FD_F2 = MW * 2 * 512; // fd[wave][ear][512]
 	static constexpr int TOTAL_F2 = SLICES_F2 + FD_F2;
+	// what is left of the CU's 160 KiB holds the history rows of the wave's sources between blocks (see HIST_LDS)
+	static constexpr int HL = (8 - SQ) * 64;
+	static constexpr int LEFT_BYTES = 160 * 1024 - TOTAL_F2 * 8 - 1024 * 8 - 64;
+	static constexpr int HIST_ROWS = LEFT_BYTES / (MW * HL * 4); // per wave: 6 at F = 512, 4 at F = 256
 };
 
 __device__ __forceinline__ void lds_wait_at_least(const uint32_t *flag, uint32_t want) {
@@ -38,7 +42,11 @@ __device__ __forceinline__ void lds_wait_at_least(const uint32_t *flag, uint32_t
 	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
-template <int SQ>
+// HIST_LDS: every wave has at most MultiLds::HIST_ROWS sources, so their history rows stay in LDS from block to block --
+// read from HBM by the first block only, written back by the last one only.  Measured before (profiles/r02_notes.md):
+// the launch runs at the fabric's rate over its actual traffic, and a row stored by block b did NOT come back out of
+// the L2 for block b + 1 (FETCH_SIZE per block barely moved) -- 16.8 of a block's 74 MB were history.
+template <int SQ, bool HIST_LDS>
 __global__ __launch_bounds__(MW * 64, GAS_HRTF_WAVES_PER_SIMD) void k_hrtf_multi(gas_group_args g, gas_hrtf_blocks mb, const uint32_t *__restrict__ peak_bits, uint32_t peak_all, gas_dev_state st, gas_hrtf_table tab, const float2 *__restrict__ tw, float *__restrict__ partials) {
 	constexpr int FQ = 2 * SQ; // F / 64
 	constexpr int HQ = 8 - SQ; // hist_len / 64
@@ -47,10 +55,12 @@ __global__ __launch_bounds__(MW * 64, GAS_HRTF_WAVES_PER_SIMD) void k_hrtf_multi
 	constexpr uint32_t HL = HQ * 64;
 	__shared__ float2 lds_all[MultiLds<SQ>::TOTAL_F2];
 	__shared__ float2 tw_lds[1024];
+	__shared__ float hist_lds[HIST_LDS ? MW * MultiLds<SQ>::HIST_ROWS * HL : 4];
 	__shared__ uint32_t arrived, consumed;
 	const int lane = threadIdx.x & 63;
 	const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-	float2 *lds = lds_all + wave * (2 * LDS_F2_HALF);
+	float2 *lds = lds_all + wave * LDS_F2_HALF;
+	float *my_hist = hist_lds + (HIST_LDS ? wave * MultiLds<SQ>::HIST_ROWS * HL : 0); // [source of this wave][HL], lane-major rows
 	float2 *fd = lds_all + MultiLds<SQ>::SLICES_F2;
 	const uint32_t K = mb.k;
 
@@ -138,10 +148,15 @@ __global__ __launch_bounds__(MW * 64, GAS_HRTF_WAVES_PER_SIMD) void k_hrtf_multi
 				finish_spectra(lane, hs);
 #pragma unroll
 				for (int j = 0; j < 8; j++) {
-					yl[j] = cmul(zp[j], make_float2(hs[j].x, hs[j].y));
-					yr[j] = cmul(zp[j], make_float2(hs[j].z, hs[j].w));
-					aYL[j] = cadd(aYL[j], yl[j]);
-					aYR[j] = cadd(aYR[j], yr[j]);
+					cmac_fixed(aYL[j], zp[j], hs[j].x, hs[j].y);
+					cmac_fixed(aYR[j], zp[j], hs[j].z, hs[j].w);
+				}
+				if (prev_flag) { // wave-uniform: this source's own output spectra (before the row's registers are requested again)
+#pragma unroll
+					for (int j = 0; j < 8; j++) {
+						yl[j] = cmul_fixed(zp[j], hs[j].x, hs[j].y);
+						yr[j] = cmul_fixed(zp[j], hs[j].z, hs[j].w);
+					}
 				}
 			}
 			if (more) {
@@ -149,7 +164,7 @@ __global__ __launch_bounds__(MW * 64, GAS_HRTF_WAVES_PER_SIMD) void k_hrtf_multi
 			}
 			if (have_prev && prev_flag) { // this source's own output, for max |L|, max |R| (audio_spatializer.cpp:436-443)
 				fft512<true>(yl, t1, t2, lds, lane); // one after the other (k_hrtf_uni interleaves the pair: same operations, same
-				fft512<true>(yr, t1, t2, lds + LDS_F2_HALF, lane); // bits, but ~20 more live registers than this kernel has)
+				fft512<true>(yr, t1, t2, lds, lane); // bits, but ~20 more live registers than this kernel has)
 				float pkl = 0.0f, pkr = 0.0f;
 #pragma unroll
 				for (int t = 0; t < SQ; t++) {
@@ -173,6 +188,9 @@ __global__ __launch_bounds__(MW * 64, GAS_HRTF_WAVES_PER_SIMD) void k_hrtf_multi
 			const float g1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_g1), (int)i));
 			const uint32_t flag = (uint32_t)__builtin_amdgcn_readlane((int)my_flag, (int)i);
 			float xq[NQ];
+			if (HIST_LDS && b > 0) { // wave-uniform: the row this wave parked in the previous block
+				load_history<HQ>(my_hist + (size_t)i * HL, lane, rawh);
+			}
 #pragma unroll
 			for (int q = 0; q < HQ; q++) {
 				xq[q] = rawh[q];
@@ -188,7 +206,13 @@ __global__ __launch_bounds__(MW * 64, GAS_HRTF_WAVES_PER_SIMD) void k_hrtf_multi
 				const float t = (lf + (float)(64 * q)) * (1.0f / (float)F);
 				xq[HQ + q] = mono * (g1 * t + (1 - t) * g0);
 			}
-			store_history<HQ>(st.hrtf_hist + (size_t)slot * HL, lane, &xq[FQ]); // new history = x_full[F .. F + HL)
+			// new history = x_full[F .. F + HL): to the slot's row, or (HIST_LDS) parked for the next block and written
+			// back by the last one only
+			if (!HIST_LDS || b + 1 == K) {
+				store_history<HQ>(st.hrtf_hist + (size_t)slot * HL, lane, &xq[FQ]);
+			} else {
+				store_history<HQ>(my_hist + (size_t)i * HL, lane, &xq[FQ]);
+			}
 			// the landing registers are free again: the next source of this block, or the first one of the next block
 			// (whose history row this wave stored earlier in this block, or just above when it has a single source)
 			const bool wrap = i + 1 == cnt;
@@ -197,7 +221,9 @@ __global__ __launch_bounds__(MW * 64, GAS_HRTF_WAVES_PER_SIMD) void k_hrtf_multi
 				const uint32_t nslot = (uint32_t)__builtin_amdgcn_readlane((int)my_slot, (int)ni);
 				const uint32_t nrow = (uint32_t)__builtin_amdgcn_readlane((int)my_row, (int)ni);
 				const gas_audio_frame *nsrc = mb.src[wrap ? b + 1 : b] + (size_t)nrow * F;
-				load_history<HQ>(st.hrtf_hist + (size_t)nslot * HL, lane, rawh);
+				if (!HIST_LDS || (b == 0 && !wrap)) { // HIST_LDS: only block 0 reads history rows from memory
+					load_history<HQ>(st.hrtf_hist + (size_t)nslot * HL, lane, rawh);
+				}
 #pragma unroll
 				for (int q = 0; q < FQ; q++) {
 					raw[q] = nt_load_frame(nsrc + lane + 64 * q);
@@ -306,19 +332,23 @@ hipError_t gas_launch_hrtf_multi(hipStream_t stream, const gas_group_args &g, co
 	}
 	dim3 grid(wgs), block(MW * 64);
 	const uint32_t all = peak_all ? 1u : 0u;
+	const uint32_t per_wave = (g.n + wgs * MW - 1) / (wgs * MW); // the most sources a wave gets (wave_range)
+#define GAS_MULTI_CASE(SQv)                                                                                                                     \
+	case SQv:                                                                                                                                   \
+		if (per_wave <= (uint32_t)MultiLds<SQv>::HIST_ROWS) {                                                                                   \
+			hipLaunchKernelGGL((k_hrtf_multi<SQv, true>), grid, block, 0, stream, g, mb, peak_bits, all, st, tab, twiddles, partials);          \
+		} else {                                                                                                                                \
+			hipLaunchKernelGGL((k_hrtf_multi<SQv, false>), grid, block, 0, stream, g, mb, peak_bits, all, st, tab, twiddles, partials);         \
+		}                                                                                                                                       \
+		break;
 	switch (frames / 128) {
-		case 1:
-			hipLaunchKernelGGL((k_hrtf_multi<1>), grid, block, 0, stream, g, mb, peak_bits, all, st, tab, twiddles, partials);
-			break;
-		case 2:
-			hipLaunchKernelGGL((k_hrtf_multi<2>), grid, block, 0, stream, g, mb, peak_bits, all, st, tab, twiddles, partials);
-			break;
-		case 3:
-			hipLaunchKernelGGL((k_hrtf_multi<3>), grid, block, 0, stream, g, mb, peak_bits, all, st, tab, twiddles, partials);
-			break;
+		GAS_MULTI_CASE(1)
+		GAS_MULTI_CASE(2)
+		GAS_MULTI_CASE(3)
+		GAS_MULTI_CASE(4)
 		default:
-			hipLaunchKernelGGL((k_hrtf_multi<4>), grid, block, 0, stream, g, mb, peak_bits, all, st, tab, twiddles, partials);
-			break;
+			return hipErrorInvalidValue;
 	}
+#undef GAS_MULTI_CASE
 	return hipGetLastError();
 }

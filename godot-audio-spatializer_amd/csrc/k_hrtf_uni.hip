@@ -218,8 +218,11 @@ __global__ __launch_bounds__(UW * 64, LEAN ? 3 : GAS_HRTF_WAVES_PER_SIMD) void k
 		if (!flag) { // wave-uniform
 #pragma unroll
 			for (int j = 0; j < 8; j++) {
-				acc[j * 64 + lane] = cadd(acc[j * 64 + lane], cmul(z[j], make_float2(hs[j].x, hs[j].y)));
-				acc[512 + j * 64 + lane] = cadd(acc[512 + j * 64 + lane], cmul(z[j], make_float2(hs[j].z, hs[j].w)));
+				float2 al = acc[j * 64 + lane], ar = acc[512 + j * 64 + lane];
+				cmac_fixed(al, z[j], hs[j].x, hs[j].y);
+				cmac_fixed(ar, z[j], hs[j].z, hs[j].w);
+				acc[j * 64 + lane] = al;
+				acc[512 + j * 64 + lane] = ar;
 			}
 			return;
 		}
@@ -230,8 +233,10 @@ __global__ __launch_bounds__(UW * 64, LEAN ? 3 : GAS_HRTF_WAVES_PER_SIMD) void k
 		for (int ear = 0; ear < 2; ear++) {
 #pragma unroll
 			for (int j = 0; j < 8; j++) {
-				y[j] = cmul(z[j], ear == 0 ? make_float2(hs[j].x, hs[j].y) : make_float2(hs[j].z, hs[j].w));
-				acc[ear * 512 + j * 64 + lane] = cadd(acc[ear * 512 + j * 64 + lane], y[j]);
+				y[j] = cmul_fixed(z[j], ear == 0 ? hs[j].x : hs[j].z, ear == 0 ? hs[j].y : hs[j].w);
+				float2 a = acc[ear * 512 + j * 64 + lane];
+				cmac_fixed(a, z[j], ear == 0 ? hs[j].x : hs[j].z, ear == 0 ? hs[j].y : hs[j].w);
+				acc[ear * 512 + j * 64 + lane] = a;
 			}
 			inv(y, lds);
 			float p = 0.0f;
@@ -254,10 +259,15 @@ __global__ __launch_bounds__(UW * 64, LEAN ? 3 : GAS_HRTF_WAVES_PER_SIMD) void k
 			finish_spectra(lane, hs);
 #pragma unroll
 			for (int j = 0; j < 8; j++) {
-				yl[j] = cmul(zp[j], make_float2(hs[j].x, hs[j].y));
-				yr[j] = cmul(zp[j], make_float2(hs[j].z, hs[j].w));
-				aYL[j] = cadd(aYL[j], yl[j]);
-				aYR[j] = cadd(aYR[j], yr[j]);
+				cmac_fixed(aYL[j], zp[j], hs[j].x, hs[j].y);
+				cmac_fixed(aYR[j], zp[j], hs[j].z, hs[j].w);
+			}
+			if (prev_flag) { // wave-uniform: this source's own output spectra (before the row's registers are requested again)
+#pragma unroll
+				for (int j = 0; j < 8; j++) {
+					yl[j] = cmul_fixed(zp[j], hs[j].x, hs[j].y);
+					yr[j] = cmul_fixed(zp[j], hs[j].z, hs[j].w);
+				}
 			}
 		}
 		if (more) {

@@ -45,6 +45,38 @@ __global__ __launch_bounds__(RED_COLS * 64) void k_mix_reduce(const float *__res
 	}
 }
 
+// The same sum for several independent (partials, out) pairs in one launch: blockIdx.y picks the pair.  What
+// gas_ctx_join_outputs runs when a batched launch left one pending sum per block.
+__global__ __launch_bounds__(RED_COLS * 64) void k_mix_reduce_jobs(gas_reduce_jobs jobs, uint32_t elems) {
+	const int lane = threadIdx.x & 63;
+	const uint32_t i4 = blockIdx.x * RED_COLS + (threadIdx.x >> 6);
+	const uint32_t e4 = elems / 4;
+	if (i4 >= e4) { // wave-uniform
+		return;
+	}
+	const uint32_t p_count = jobs.p_count[blockIdx.y];
+	float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+	const float4 *p = reinterpret_cast<const float4 *>(jobs.partials[blockIdx.y]) + i4;
+	uint32_t k = lane;
+	for (; k + 3 * 64 < p_count; k += 4 * 64) {
+		const float4 a0 = p[(size_t)k * e4];
+		const float4 a1 = p[(size_t)(k + 64) * e4];
+		const float4 a2 = p[(size_t)(k + 128) * e4];
+		const float4 a3 = p[(size_t)(k + 192) * e4];
+		gas_mix_column_add(s, a0);
+		gas_mix_column_add(s, a1);
+		gas_mix_column_add(s, a2);
+		gas_mix_column_add(s, a3);
+	}
+	for (; k < p_count; k += 64) {
+		gas_mix_column_add(s, p[(size_t)k * e4]);
+	}
+	const float4 t = gas_mix_column_fold(s);
+	if (lane == 0) {
+		reinterpret_cast<float4 *>(jobs.out[blockIdx.y])[i4] = t;
+	}
+}
+
 __global__ void k_scatter_params(gas_params *__restrict__ table, const gas_params *__restrict__ upload, const uint32_t *__restrict__ slots, uint32_t n) {
 	// 8 lanes move one 128-byte POD as 16-byte pieces
 	const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -443,6 +475,16 @@ hipError_t gas_launch_dir_order(hipStream_t stream, const gas_group_args &g, con
 		}
 	}
 	hipLaunchKernelGGL(k_dir_order, dim3((g.n + DIR_SEG - 1) / DIR_SEG), dim3(DIR_WAVES * 64), lds, stream, g, params, fresh, d2, order);
+	return hipGetLastError();
+}
+
+hipError_t gas_launch_mix_reduce_jobs(hipStream_t stream, const gas_reduce_jobs &jobs, uint32_t frames) {
+	if (jobs.count == 0) {
+		return hipSuccess;
+	}
+	const uint32_t elems = frames * 2;
+	dim3 grid((elems / 4 + RED_COLS - 1) / RED_COLS, jobs.count);
+	hipLaunchKernelGGL(k_mix_reduce_jobs, grid, dim3(RED_COLS * 64), 0, stream, jobs, elems);
 	return hipGetLastError();
 }
 

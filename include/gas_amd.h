@@ -182,7 +182,7 @@ void gas_ctx_destroy(gas_ctx *ctx);
 /* Run on an existing HIP stream (hipStream_t) instead of the context's own. */
 int gas_ctx_set_stream(gas_ctx *ctx, void *hip_stream);
 int gas_ctx_synchronize(gas_ctx *ctx);
-/* GAS_FLAG_BATCHED_LAUNCH: callbacks per launch, 1 (off) .. 8; takes effect with the next batch. */
+/* GAS_FLAG_BATCHED_LAUNCH: callbacks per launch, 1 (off) .. 16; takes effect with the next batch. */
 int gas_ctx_set_batch_depth(gas_ctx *ctx, uint32_t depth);
 /* GAS_FLAG_PIPELINED_MIX: enqueue the deferred sum of the last gas_process_block, so that work enqueued on the
  * context's stream after this call sees its `out`.  Non-blocking; no-op when nothing is pending. */

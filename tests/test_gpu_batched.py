@@ -85,7 +85,7 @@ CASES = {
 _BASE = {}
 
 
-@pytest.mark.parametrize("depth", [2, 3, 8])
+@pytest.mark.parametrize("depth", [2, 3, 8, 16])
 @pytest.mark.parametrize("case", list(CASES))
 def test_batched_launch_is_bitwise_the_ordered_mode(gas, case, depth):
     K = gas.capi
@@ -142,7 +142,7 @@ def test_batched_launch_really_batches(gas):
         ctx.synchronize()
         assert ctx.profile_read()["launches"] == 1
         with pytest.raises(gas.GasError):
-            ctx.set_batch_depth(9)
+            ctx.set_batch_depth(17)
         ctx.profile_enable(0)
     finally:
         ctx.close()
