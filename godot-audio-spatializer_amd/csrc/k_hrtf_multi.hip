@@ -17,6 +17,10 @@
 // with device-published rows (fresh[b]) takes gain and direction from them, any other repeats the previous block's.
 // Callers: gas_ctx.hip batches consecutive gas_process_block calls of an unchanged list (GAS_FLAG_BATCHED_LAUNCH: calls
 // are recorded until the batch is full; gas_ctx_join_outputs / gas_ctx_synchronize / any other entry runs what waits).
+// Source rows are loaded non-temporal here: in a batched launch the HRIR rows ARE reused (the next block of an unchanged
+// direction meets them again), and once-touched frames that do not displace them from the L2 are worth 4.5 % of the
+// launch (10.65 vs 11.15 us per block, profiles/r02_notes.md).  The single-block kernels show no difference.
+#define GAS_USE_NT 1
 #include "gas_hrtf_wave.h"
 
 namespace {
