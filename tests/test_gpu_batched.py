@@ -77,6 +77,8 @@ CASES = {
     "f128": dict(n=2048, F=128, T=5, events={2: ["dev_publish"]}),
     "many_per_wave": dict(n=9000, F=512, T=6, events={0: ["dev_publish"], 2: ["dev_publish"], 4: ["dev_publish"]}),
     "too_small_to_pair": dict(n=700, F=512, T=6, events={0: ["dev_publish"], 2: ["dev_publish"]}),
+    "hist_through_memory": dict(n=14500, F=512, T=5, events={0: ["dev_publish"], 2: ["dev_publish"], 3: ["dev_publish"]}),  # 8 sources per wave: history rows do not fit the LDS
+    "f256_hist_through_memory": dict(n=10000, F=256, T=5, events={1: ["dev_publish"]}),
     "long_run": dict(n=2048, F=512, T=21, events={t: ["dev_publish"] for t in range(0, 21, 2)}),
     "long_run_with_breaks": dict(n=2200, F=512, T=23, events={3: ["dev_publish"], 5: ["host_publish"], 9: ["join"], 10: ["dev_publish"], 13: ["relist"], 14: ["dev_publish"], 19: ["host_call"]}),
 }
