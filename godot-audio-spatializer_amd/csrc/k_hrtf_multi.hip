@@ -92,7 +92,7 @@ __global__ __launch_bounds__(MW * 64, GAS_HRTF_WAVES_PER_SIMD) void k_hrtf_multi
 		load_history<HQ>(st.hrtf_hist + (size_t)s0 * HL, lane, rawh);
 #pragma unroll
 		for (int q = 0; q < FQ; q++) {
-			raw[q] = nt_load_frame(mb.src[0] + (size_t)r0 * F + lane + 64 * q);
+			raw[q] = (GAS_ABL & 8) ? gas_audio_frame{ (float)lane, (float)r0 } : nt_load_frame(mb.src[0] + (size_t)r0 * F + lane + 64 * q);
 		}
 	}
 	// gain and direction of block b for this lane's source: its device-published row, else what it had
@@ -230,7 +230,7 @@ __global__ __launch_bounds__(MW * 64, GAS_HRTF_WAVES_PER_SIMD) void k_hrtf_multi
 				}
 #pragma unroll
 				for (int q = 0; q < FQ; q++) {
-					raw[q] = nt_load_frame(nsrc + lane + 64 * q);
+					raw[q] = (GAS_ABL & 8) ? gas_audio_frame{ (float)lane, (float)nrow } : nt_load_frame(nsrc + lane + 64 * q);
 				}
 			}
 			float2 zs[8];
