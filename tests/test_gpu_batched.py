@@ -148,3 +148,45 @@ def test_batched_launch_really_batches(gas):
         ctx.profile_enable(0)
     finally:
         ctx.close()
+
+
+def test_batched_launch_soak_against_the_unbatched_mode(gas):
+    """600 callbacks at depth 10 with a publish pattern that does not line up with the batches, against one launch per
+    callback: bitwise, every callback.  (The hand-over inside k_hrtf_multi is a pair of LDS counters; this is the long
+    run that would show a lost or early hand-over as a wrong mix.)"""
+    import torch
+
+    from godot_audio_spatializer_amd import synth
+
+    K = gas.capi
+    n, F, T, dirs = 4096, 512, 600, 64
+    hrir = synth.synthetic_hrir(np.random.default_rng(7), dirs=dirs)
+    rng = np.random.default_rng(5)
+    pool = [torch.from_numpy(synth.draw_sources(rng, n, F)).cuda() for _ in range(12)]
+    psets = [torch.from_numpy(synth.draw_params(rng, n, dirs=dirs, frames=F).view(np.uint8).reshape(n, -1).copy()).cuda() for _ in range(5)]
+    first = synth.draw_params(rng, n, dirs=dirs, frames=F)
+    res = {}
+    for name, flags in (("one", K.FLAG_PEAKS_DRAINING_ONLY | K.FLAG_PIPELINED_MIX), ("batched", K.FLAG_PEAKS_DRAINING_ONLY | K.FLAG_PIPELINED_MIX | K.FLAG_BATCHED_LAUNCH)):
+        ctx = gas.SpatializerContext(max_sources=n, frames=F, flags=flags)
+        ctx.hrtf_load(hrir)
+        if name == "batched":
+            ctx.set_batch_depth(10)
+        slots = ctx.source_alloc_many(n, K.KIND_EFFECT, (K.FX_HRTF,))
+        for s in slots[::13]:
+            ctx.source_set_draining(s, True)
+        ctx.params_publish_batch(slots, first)
+        outs = torch.full((T, 1, F, 2), float("nan"), device="cuda")
+        peaks = torch.zeros(n, 2, device="cuda")
+        torch.cuda.synchronize()
+        for t in range(T):
+            if t > 0 and t % 3 == 0:
+                ctx.params_publish_device(psets[(t // 3) % len(psets)].data_ptr(), n)
+            assert ctx.process_block_raw(pool[t % len(pool)].data_ptr(), slots if t == 0 else None, n, F, outs[t].data_ptr(), peaks.data_ptr(), K.MEM_DEVICE) == 0
+            if t % 97 == 96:
+                ctx.join_outputs()
+        ctx.synchronize()
+        res[name] = (outs.cpu().numpy(), peaks.cpu().numpy())
+        ctx.close()
+    assert not np.isnan(res["one"][0]).any()
+    assert np.array_equal(res["one"][0], res["batched"][0])
+    assert np.array_equal(res["one"][1], res["batched"][1])
