@@ -190,6 +190,7 @@ class Runner:
         self.comm_stream = torch.cuda.Stream() if env["world"] > 1 else None
         self.reducer = sharding.PartialMixReducer(env["dist"] if env["world"] > 1 else None, root=0, comm_stream=self.comm_stream)
         self.pending = [None, None]
+        self.owed = [False, False]
         rc = self.ctx.process_block_raw(self.srcs[0].data_ptr(), self.slots, n_local, frames, self.buckets[0][0].data_ptr(), self.peaks.data_ptr(), gas.capi.MEM_DEVICE)
         if rc != 0:
             raise SystemExit(f"gas_process_block failed: {rc}")
@@ -209,6 +210,7 @@ class Runner:
         if i == 0:
             self.reducer.wait(self.pending[b])  # the bucket's previous reduce must be done before it is rewritten
             self.pending[b] = None
+            self.owed[b] = True  # this bucket is being filled: it owes rank 0 one reduce
         rc = ctx.process_block_raw(self.src_ptr[k % self.n_bufs], None, n, F, self.out_ptr[b][i], self.peaks_ptr, 1)
         if rc != 0:
             raise SystemExit(f"gas_process_block failed: {rc}")
@@ -220,18 +222,23 @@ class Runner:
                 if self.depth > 1 and not aligned and self.env["world"] > 1:
                     ctx.join_outputs()  # buckets and batches do not line up: run what waits, sum what is pending
                 self.pending[1 - b] = self.reducer.reduce(self.buckets[1 - b])
+                self.owed[1 - b] = False
         elif i == B - 1:
             self.pending[b] = self.reducer.reduce(self.buckets[b])
+            self.owed[b] = False
 
     def drain(self, k_end):
         # the bucket holding the last callback still has to reach rank 0: always in pipelined mode (its reduce is
         # issued one callback late), else only when it is partly filled
         B = self.B
-        if k_end > 0 and (self.pipelined or k_end % B != 0):
-            b = ((k_end - 1) // B) % 2
-            self.reducer.wait(self.pending[b])
-            self.ctx.join_outputs()  # enqueue the pending sum of the last callback
-            self.pending[b] = self.reducer.reduce(self.buckets[b])
+        if k_end > 0 and any(self.owed):
+            self.ctx.join_outputs()  # run what waits for its batch, enqueue the pending sums
+            last = ((k_end - 1) // B) % 2
+            for b in (1 - last, last):  # the older bucket first (batched launches can leave both owing)
+                if self.owed[b]:
+                    self.reducer.wait(self.pending[b])
+                    self.pending[b] = self.reducer.reduce(self.buckets[b])
+                    self.owed[b] = False
         for i in range(2):
             self.reducer.wait(self.pending[i])
             self.pending[i] = None
