@@ -326,7 +326,7 @@ def main():
     ap.add_argument("--reduce-bucket", type=int, default=32, help="callbacks per cross-GPU reduce (N > 1); 1 = every callback's mix is reduced on its own (real-time arrangement)")
     ap.add_argument("--crossfade", action="store_true", help="GAS_FLAG_HRTF_CROSSFADE: blend old/new HRIRs when a source's direction changes (SURVEY 8f#4)")
     ap.add_argument("--no-pipelined-mix", action="store_true", help="headline without GAS_FLAG_PIPELINED_MIX: the partial-mix sum of callback t runs before callback t+1's DSP kernel instead of under it")
-    ap.add_argument("--no-paired-launch", action="store_true", help="throughput mode without GAS_FLAG_BATCHED_LAUNCH: one k_hrtf_uni launch per callback instead of one k_hrtf_multi launch per --batch-depth callbacks")
+    ap.add_argument("--no-batched-launch", action="store_true", help="throughput mode without GAS_FLAG_BATCHED_LAUNCH: one k_hrtf_uni launch per callback instead of one k_hrtf_multi launch per --batch-depth callbacks")
     ap.add_argument("--batch-depth", type=int, default=10, help="GAS_FLAG_BATCHED_LAUNCH: callbacks per k_hrtf_multi launch (2 .. 16)")
     ap.add_argument("--direction-order", action="store_true", help="GAS_FLAG_DIRECTION_ORDER: let the library group sources by HRIR direction (device sort per publish)")
     ap.add_argument("--presorted-directions", action="store_true", help="GAS_FLAG_DIRECTION_RUNS with parameters whose HRIR directions are grouped in callback order (what a caller that sorts its list gets)")
@@ -365,7 +365,7 @@ def main():
     if args.sources_per_gpu and args.sources_per_gpu != n_default:
         desc += f" -- run with {args.sources_per_gpu} sources/GPU instead"
     # anything that makes the run something other than the workload as described (PMC records only match like with like)
-    experiment = " ".join(f for f, on in (("--no-paired-launch", args.no_paired_launch and not args.no_pipelined_mix), ("--xcd-directions", args.xcd_directions), ("--xcd-order", args.xcd_order), ("--direction-order", args.direction_order), ("--presorted-directions", args.presorted_directions), ("--crossfade", args.crossfade)) if on)
+    experiment = " ".join(f for f, on in (("--no-batched-launch", args.no_batched_launch and not args.no_pipelined_mix), ("--xcd-directions", args.xcd_directions), ("--xcd-order", args.xcd_order), ("--direction-order", args.direction_order), ("--presorted-directions", args.presorted_directions), ("--crossfade", args.crossfade)) if on)
     n_local = args.sources_per_gpu or n_default
     n_total = n_local * world
     begin, end = sharding.shard_range(n_total, rank, world)
@@ -387,7 +387,7 @@ def main():
         base_flags |= K.FLAG_DIRECTION_RUNS
     if args.xcd_order:
         base_flags |= K.FLAG_XCD_ORDER
-    head_flags = base_flags | (0 if args.no_pipelined_mix else K.FLAG_PIPELINED_MIX | (0 if args.no_paired_launch else K.FLAG_BATCHED_LAUNCH))
+    head_flags = base_flags | (0 if args.no_pipelined_mix else K.FLAG_PIPELINED_MIX | (0 if args.no_batched_launch else K.FLAG_BATCHED_LAUNCH))
 
     # ---- headline pass: exactly --steps callbacks, no markers inside -----------------------------------------------
     run = Runner(env, head_flags, n_local, args.reduce_bucket)
@@ -425,7 +425,7 @@ def main():
             "wall_ms_per_step": wall_ms / args.steps,
             "config": {
                 "workload": desc,
-                "mode": ("ordered (synchronous two-dispatch callback)" if args.no_pipelined_mix else "throughput: callbacks queued back to back, GAS_FLAG_PIPELINED_MIX (the sum of callback t's partial mixes rides in a later launch)" + ("" if args.no_paired_launch else f" + GAS_FLAG_BATCHED_LAUNCH ({args.batch_depth} consecutive callbacks per launch; outputs complete at gas_ctx_join_outputs)")) + ("" if args.exact_peaks else " + GAS_FLAG_PEAKS_DRAINING_ONLY"),
+                "mode": ("ordered (synchronous two-dispatch callback)" if args.no_pipelined_mix else "throughput: callbacks queued back to back, GAS_FLAG_PIPELINED_MIX (the sum of callback t's partial mixes rides in a later launch)" + ("" if args.no_batched_launch else f" + GAS_FLAG_BATCHED_LAUNCH ({args.batch_depth} consecutive callbacks per launch; outputs complete at gas_ctx_join_outputs)")) + ("" if args.exact_peaks else " + GAS_FLAG_PEAKS_DRAINING_ONLY"),
                 "timing": f"one HIP event pair on the launch stream around the {args.steps} callbacks (GPU timeline), {CONDITION_STEPS} untimed conditioning callbacks in front, max over ranks; wall_ms_per_step = host clock around the same region incl. the closing synchronize",
                 "parity": "unpinned: HRTF / early reflections have no reference counterpart, outputs are checked against this repository's oracle (DESIGN.md section 0)" if (3 in chain or 2 in chain) else "oracle restates audio_spatializer_3d.cpp:554-609; engine primitives unpinned (DESIGN.md section 0)",
                 "sources_total": n_total,
