@@ -703,6 +703,7 @@ int flush_deferred(gas_ctx *c) {
 	if (c->deferred.empty()) {
 		return GAS_OK;
 	}
+	GAS_HIP(c, hipSetDevice(c->cfg.device)); // callers flush before they do anything else, device selection included
 	const std::vector<gas_ctx::Deferred> blocks = std::move(c->deferred);
 	c->deferred.clear();
 	if (blocks.size() > 1) {
