@@ -1497,6 +1497,12 @@ int gas_params_publish_batch(gas_ctx *c, const uint32_t *slots, const gas_params
 		}
 		// Deferred: the next gas_process_block over this same list consumes the rows in its own launch when it can
 		// (all sources plain HRTF), else scatters them first.  The buffer must stay untouched until then.
+		if (c->pending_params) { // an earlier publish nobody consumed is about to be scattered: recorded callbacks first
+			const int rcd = flush_deferred(c);
+			if (rcd != GAS_OK) {
+				return rcd;
+			}
+		}
 		int rcp = flush_pending_params(c);
 		if (rcp != GAS_OK) {
 			return rcp;

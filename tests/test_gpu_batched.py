@@ -39,11 +39,12 @@ def _render(gas, flags, n, F, T, events, dirs=48, depth=None):
         if "dev_publish" in ev and t == 0:  # the device form addresses the previous callback's list: none yet
             ctx.params_publish_batch(slots, synth.draw_params(rng, n, dirs=dirs, frames=F))
         elif "dev_publish" in ev:
-            p = synth.draw_params(rng, n, dirs=dirs, frames=F)
-            d_p = torch.from_numpy(p.view(np.uint8).reshape(n, -1).copy()).cuda()
-            keep.append(d_p)
-            torch.cuda.synchronize()
-            ctx.params_publish_device(d_p.data_ptr(), n)
+            for _ in range(list(ev).count("dev_publish")):  # twice in a row: the first one is scattered, not consumed
+                p = synth.draw_params(rng, n, dirs=dirs, frames=F)
+                d_p = torch.from_numpy(p.view(np.uint8).reshape(n, -1).copy()).cuda()
+                keep.append(d_p)
+                torch.cuda.synchronize()
+                ctx.params_publish_device(d_p.data_ptr(), n)
         if "join" in ev:
             ctx.join_outputs()
         if "host_call" in ev:
@@ -79,6 +80,7 @@ CASES = {
     "too_small_to_pair": dict(n=700, F=512, T=6, events={0: ["dev_publish"], 2: ["dev_publish"]}),
     "hist_through_memory": dict(n=14500, F=512, T=5, events={0: ["dev_publish"], 2: ["dev_publish"], 3: ["dev_publish"]}),  # 8 sources per wave: history rows do not fit the LDS
     "f256_hist_through_memory": dict(n=10000, F=256, T=5, events={1: ["dev_publish"]}),
+    "two_device_publishes_in_a_row": dict(n=2048, F=512, T=7, events={2: ["dev_publish", "dev_publish"], 3: ["dev_publish"], 5: ["dev_publish", "dev_publish"]}),
     "long_run": dict(n=2048, F=512, T=21, events={t: ["dev_publish"] for t in range(0, 21, 2)}),
     "long_run_with_breaks": dict(n=2200, F=512, T=23, events={3: ["dev_publish"], 5: ["host_publish"], 9: ["join"], 10: ["dev_publish"], 13: ["relist"], 14: ["dev_publish"], 19: ["host_call"]}),
 }
