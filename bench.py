@@ -435,6 +435,7 @@ def main():
                 "hrir_directions": args.dirs if hrir is not None else 0,
                 "hrir_crossfade": bool(args.crossfade),
                 "pipelined_mix": not args.no_pipelined_mix,
+                "callbacks_per_launch": run.depth,
                 "host_enqueue_us_per_step": enq_ms / args.steps * 1e3,
                 "peaks": peaks_desc,
                 "experiment": experiment,
