@@ -192,3 +192,27 @@ def test_batched_launch_soak_against_the_unbatched_mode(gas):
     assert not np.isnan(res["one"][0]).any()
     assert np.array_equal(res["one"][0], res["batched"][0])
     assert np.array_equal(res["one"][1], res["batched"][1])
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_batched_launch_random_event_sequences(gas, seed):
+    """Random sizes, frame counts, depths and event sequences: batched == ordered, bitwise."""
+    K = gas.capi
+    rng = np.random.default_rng(400 + seed)
+    n = int(rng.integers(2048, 7000))
+    F = int(rng.choice([128, 256, 384, 512]))
+    T = int(rng.integers(6, 30))
+    depth = int(rng.integers(2, 17))
+    names = ["dev_publish", "host_publish", "join", "relist", "host_call"]
+    weights = [0.45, 0.15, 0.15, 0.15, 0.10]
+    events = {}
+    for t in range(T):
+        if rng.random() < 0.4:
+            events[t] = [str(rng.choice(names, p=weights))]
+    peaks_flag = K.FLAG_PEAKS_DRAINING_ONLY if rng.random() < 0.7 else 0
+    args = dict(n=n, F=F, T=T, events=events)
+    base, pk0 = _render(gas, peaks_flag, **args)
+    got, pk1 = _render(gas, peaks_flag | K.FLAG_PIPELINED_MIX | K.FLAG_BATCHED_LAUNCH, depth=depth, **args)
+    assert not np.isnan(base).any()
+    assert np.array_equal(base, got), f"seed {seed}: n {n} F {F} T {T} depth {depth} events {events}"
+    assert np.array_equal(pk0, pk1)
