@@ -439,9 +439,18 @@ int run_groups(gas_ctx *c, const gas_audio_frame *d_src, const uint32_t *d_slots
 	// GAS_FLAG_PIPELINED_MIX: only callbacks that are one channel pair wide and carry an HRTF launch defer their sum
 	// A launch can carry the pending sum when it is the plain [HRTF] kernel (register budget), covers every output
 	// column with a workgroup and the pending callback left at most 256 partial rows (k_hrtf_ols: job_issue).
+	// The plain [HRTF] launch takes it when there is one, else the [ER, HRTF] launch.
 	bool carrier = false;
-	if (groups[G_FX_HRTF].count + groups[G_FX_HRTF_PK].count > 0 && !c->fused_streams && (c->cfg.flags & GAS_FLAG_HRTF_CROSSFADE) == 0) {
-		carrier = (pcount[G_FX_HRTF] + pcount[G_FX_HRTF_PK]) * GAS_HRTF_JOB_WAVES >= F * 2 / 4 && c->pending_mix.p_total <= 256;
+	int carrier_gt = -1;
+	if (!c->fused_streams && (c->cfg.flags & GAS_FLAG_HRTF_CROSSFADE) == 0) {
+		for (int gt : { (int)G_FX_HRTF, (int)G_FX_ER_HRTF }) {
+			if (carrier_gt < 0 && groups[gt].count + groups[gt + 1].count > 0) {
+				carrier_gt = gt;
+			}
+		}
+	}
+	if (carrier_gt >= 0) {
+		carrier = (pcount[carrier_gt] + pcount[carrier_gt + 1]) * GAS_HRTF_JOB_WAVES >= F * 2 / 4 && c->pending_mix.p_total <= 256;
 	}
 	pipelined = pipelined && c->pipelined_mix && channel_count == 1 && c->cfg.channel_count == 1;
 	int rc = GAS_OK;
@@ -561,7 +570,7 @@ int run_groups(gas_ctx *c, const gas_audio_frame *d_src, const uint32_t *d_slots
 				}
 				// GAS_FLAG_DIRECTION_ORDER: direction order of the frequency-domain group, rebuilt when the
 				// callback's list or any parameter changed, else reused.  Only when directions repeat within a segment.
-				const gas_params *fresh = fd_gt == G_FX_HRTF ? c->fresh_for_launch : nullptr;
+				const gas_params *fresh = c->fresh_for_launch; // both HRTF forms read device-published rows themselves and write them through
 				if (gt == G_FX_HRTF && gp.count == 0 && uni_hrtf) {
 					// the whole plain-[HRTF] group in one uniform launch (k_hrtf_uni.hip)
 					// XCD-affine processing order (k_xcd_order): rebuilt when the list or any parameter changed, else reused
@@ -598,8 +607,8 @@ int run_groups(gas_ctx *c, const gas_audio_frame *d_src, const uint32_t *d_slots
 						g_fd.order = ord;
 					}
 				}
-				e = gas_launch_hrtf_ols(c->stream, fd_gt == G_FX_ER_HRTF, (c->cfg.flags & GAS_FLAG_HRTF_CROSSFADE) != 0, (c->cfg.flags & (GAS_FLAG_DIRECTION_RUNS | GAS_FLAG_DIRECTION_ORDER)) != 0, g_fd, g_pk, c->st, c->tab, c->d_tw, F, c->hist_len, c->cfg.er_ring_frames, parts, p_off, fd_gt == G_FX_HRTF && c->fused_streams ? c->d_cursors : nullptr, c->d_fade_env, fresh, fd_gt == G_FX_HRTF ? job : gas_deferred_reduce());
-				if (fd_gt == G_FX_HRTF) {
+				e = gas_launch_hrtf_ols(c->stream, fd_gt == G_FX_ER_HRTF, (c->cfg.flags & GAS_FLAG_HRTF_CROSSFADE) != 0, (c->cfg.flags & (GAS_FLAG_DIRECTION_RUNS | GAS_FLAG_DIRECTION_ORDER)) != 0, g_fd, g_pk, c->st, c->tab, c->d_tw, F, c->hist_len, c->cfg.er_ring_frames, parts, p_off, fd_gt == G_FX_HRTF && c->fused_streams ? c->d_cursors : nullptr, c->d_fade_env, fresh, fd_gt == carrier_gt ? job : gas_deferred_reduce());
+				if (fd_gt == carrier_gt) {
 					carried_bytes = job.partials ? ((uint64_t)job.p_count + 1) * job.elems * sizeof(float) : 0;
 					job = gas_deferred_reduce();
 				}
@@ -2059,7 +2068,7 @@ int gas_process_block(gas_ctx *c, const gas_audio_frame *src, const uint32_t *sl
 	if (c->pending_params) {
 		bool only_hrtf = true;
 		for (int gt = 0; gt < G_COUNT; gt++) {
-			only_hrtf = only_hrtf && (gt == G_FX_HRTF || gt == G_FX_HRTF_PK || c->groups[gt].count == 0);
+			only_hrtf = only_hrtf && (gt == G_FX_HRTF || gt == G_FX_HRTF_PK || gt == G_FX_ER_HRTF || gt == G_FX_ER_HRTF_PK || c->groups[gt].count == 0);
 		}
 		if (only_hrtf && c->pending_n == n) {
 			c->fresh_for_launch = c->pending_params; // k_hrtf_ols reads the rows and writes them through

@@ -91,7 +91,8 @@ __device__ __forceinline__ void hrtf_body(float2 *lds_all, float2 *tw_lds, const
 
 	// GAS_FLAG_PIPELINED_MIX: one wave also sums the previous callback's partial mixes for one output column
 	// (waves 2 .. 5, idle while waves 0 and 1 run the frequency-domain epilogue's inverse FFTs, take one column each)
-	constexpr bool JOB_OK = !WITH_ER && !SRC_PCM && !XFADE; // register budget: the plain chain only
+	constexpr bool JOB_OK = !SRC_PCM && !XFADE; // register budget: not the stream-sampling and cross-fade forms
+	constexpr bool JOB_LATE = WITH_ER; // early reflections: no 16 registers to park the rows across the loop -- they are requested where they are summed
 	float4 jr[JOB_ROWS];
 	bool job_mine = false;
 	if constexpr (JOB_OK) {
@@ -101,7 +102,7 @@ __device__ __forceinline__ void hrtf_body(float2 *lds_all, float2 *tw_lds, const
 		const uint32_t jw = (uint32_t)(wave - 2), jx = job_col & 7, ji = job_col >> 3;
 		job_col = (((ji >> 1) * 8 + jx) * 8) + (ji & 1) * 4 + jw;
 		job_mine = job.partials != nullptr && wave >= 2 && jw < GAS_HRTF_JOB_WAVES && job_col < job.elems / 4; // wave-uniform
-		if (job_mine) {
+		if (job_mine && !JOB_LATE) {
 			job_issue(job, job_col, lane, jr);
 		}
 	}
@@ -276,7 +277,7 @@ __device__ __forceinline__ void hrtf_body(float2 *lds_all, float2 *tw_lds, const
 		if constexpr (WITH_ER) {
 			// early reflections (oracle fx_early_reflections): taps in order, f32.  The 64 gathers per
 			// lane run in a rolled loop and hand their result over through the wave's LDS slice.
-			const gas_params *P = st.params + m.slot;
+			const gas_params *P = fresh ? fresh + m.row : st.params + m.slot; // device-published rows of this callback, not yet in the table
 			const gas_audio_frame *srow = g.src + (size_t)m.row * F;
 			const uint32_t er_pos = st.er_pos[m.slot];
 			gas_audio_frame *ring = st.er_ring + (size_t)m.slot * er_R;
@@ -527,6 +528,9 @@ __device__ __forceinline__ void hrtf_body(float2 *lds_all, float2 *tw_lds, const
 		}
 		if constexpr (JOB_OK) {
 			if (job_mine) {
+				if (JOB_LATE) {
+					job_issue(job, job_col, lane, jr);
+				}
 				job_finish(job, job_col, lane, jr);
 			}
 		}
@@ -585,6 +589,9 @@ __device__ __forceinline__ void hrtf_body(float2 *lds_all, float2 *tw_lds, const
 			}
 			if constexpr (JOB_OK) {
 				if (job_mine && round == 0) { // waves 2.. idle while 0 and 1 transform: the previous callback's sum
+					if (JOB_LATE) {
+						job_issue(job, job_col, lane, jr);
+					}
 					job_finish(job, job_col, lane, jr);
 				}
 			}
@@ -897,7 +904,7 @@ hipError_t gas_launch_hrtf_ols(hipStream_t stream, bool with_er, bool crossfade,
 	if (g_fd.n + g_pk.n == 0) {
 		return hipSuccess;
 	}
-	if (frames % 128 != 0 || frames > 512 || hist_len != 512 - frames / 2 || (with_er && (cursors || fresh))) {
+	if (frames % 128 != 0 || frames > 512 || hist_len != 512 - frames / 2 || (with_er && cursors)) {
 		return hipErrorInvalidValue;
 	}
 	gas_hrtf_launch_plan plan;
