@@ -484,12 +484,9 @@ int run_groups(gas_ctx *c, const gas_audio_frame *d_src, const uint32_t *d_slots
 		job.out = reinterpret_cast<float *>(c->pending_mix.out);
 		c->pending_mix.valid = false;
 	}
-	// only k_biquad_mix accumulates peaks (atomicMax over channel pairs); the other kernels store them
-	bool biquad_groups = false;
-	for (int gt = G_3D_MIX; gt <= G_FX_SHELF; gt++) {
-		biquad_groups = biquad_groups || groups[gt].count > 0;
-	}
-	if (biquad_groups) {
+	// only the mix_channel launch over several channel pairs accumulates peaks (atomicMax over the pairs, from zero);
+	// every other launch -- a single pair included -- stores them, so the zeroing pass (a 4 us dispatch) is skipped
+	if (groups[G_3D_MIX].count + groups[G_3D_PROCESS].count > 0 && channel_count > 1 && force_mode != GAS_MODE_PROCESS_FRAMES) {
 		GAS_HIP(c, hipMemsetAsync(d_peaks, 0, (size_t)n_total * 2 * sizeof(float), c->stream));
 	}
 

@@ -371,7 +371,11 @@ __global__ __launch_bounds__(64) void k_biquad_mix(gas_group_args g, gas_dev_sta
 		}
 		// per-source peak over all its channel pairs (:419-444): max is order-independent
 		if (!rows_out) {
-			atomicMax(reinterpret_cast<unsigned int *>(g.peaks) + (size_t)row * 2 + ear, __float_as_uint(peak));
+			if (gridDim.y == 1) { // one channel pair: this lane is the only writer (and the context skips the zeroing pass)
+				g.peaks[(size_t)row * 2 + ear] = peak;
+			} else {
+				atomicMax(reinterpret_cast<unsigned int *>(g.peaks) + (size_t)row * 2 + ear, __float_as_uint(peak));
+			}
 		}
 	}
 }

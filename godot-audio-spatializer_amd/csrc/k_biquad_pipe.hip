@@ -439,7 +439,11 @@ __global__ __launch_bounds__(N_WAVES * 64) void k_biquad_pipe(gas_group_args g, 
 	}
 	if (role == R_REC) {
 		// per-source peak over all its channel pairs (:419-444): max is order-independent
-		atomicMax(reinterpret_cast<unsigned int *>(g.peaks) + (size_t)row * 2 + ear, __float_as_uint(peak));
+		if (gridDim.y == 1) { // one channel pair: this lane is the only writer (and the context skips the zeroing pass)
+			g.peaks[(size_t)row * 2 + ear] = peak;
+		} else {
+			atomicMax(reinterpret_cast<unsigned int *>(g.peaks) + (size_t)row * 2 + ear, __float_as_uint(peak));
+		}
 	}
 	if (role == R_COEF && filt) {
 		bq[BQ_B0 * bs + stream] = b0;
