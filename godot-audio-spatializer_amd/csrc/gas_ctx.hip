@@ -88,6 +88,8 @@ struct gas_ctx {
 	uint32_t deferred_n = 0;
 	uint64_t deferred_groups_gen = 0;
 	uint32_t batch_depth = 2; // callbacks per launch (gas_ctx_set_batch_depth), <= GAS_HRTF_MULTI_MAX_BLOCKS
+	bool force_staged = false; // gas_process_block_buses over effect kinds: every chain runs staged (rows out), the rows are mixed per bus
+	const gas_bus_args *run_buses = nullptr; // set for the duration of that run_groups
 	uint32_t partial_planes = 1; // planes of d_partials (1 ordered, 2 pipelined, 2 x max batch depth batched)
 	bool prof_multi = false; // the timed launch was k_hrtf_multi
 	uint32_t hist_len = 0;
@@ -470,7 +472,7 @@ int run_groups(gas_ctx *c, const gas_audio_frame *d_src, const uint32_t *d_slots
 			return rc;
 		}
 	}
-	rc = ensure_partials(c, p_total > 0 ? p_total : 1);
+	rc = ensure_partials(c, (p_total > 0 ? p_total : 1) * (c->run_buses ? c->run_buses->n_buses : 1u)); // buses: p_total rows per bus, bus after bus
 	if (rc != GAS_OK) {
 		return rc;
 	}
@@ -656,7 +658,11 @@ int run_groups(gas_ctx *c, const gas_audio_frame *d_src, const uint32_t *d_slots
 					if (e == hipSuccess) {
 						gas_group_args fin = in;
 						fin.rows = peak_rows; // peaks go to the callback's row of each source
-						e = gas_launch_rows_accumulate(c->stream, fin, F, parts, pp);
+						if (c->run_buses) {
+							e = gas_launch_rows_accumulate_buses(c->stream, fin, F, c->run_buses->routes, c->run_buses->n_buses, p_total, parts, pp);
+						} else {
+							e = gas_launch_rows_accumulate(c->stream, fin, F, parts, pp);
+						}
 					}
 					pp += gas_hrtf_partials(r.count);
 				}
@@ -692,6 +698,10 @@ int run_groups(gas_ctx *c, const gas_audio_frame *d_src, const uint32_t *d_slots
 		c->pending_mix.p_total = p_total;
 		c->pending_mix.out = d_out;
 		c->pipe_tick++;
+		return GAS_OK;
+	}
+	if (c->run_buses) { // out[b][F]: bus b's rows are [b * p_total, (b + 1) * p_total)
+		GAS_HIP(c, gas_launch_mix_reduce(c->stream, parts, p_total, p_total > 0 ? p_total : 1, c->run_buses->n_buses, F, d_out));
 		return GAS_OK;
 	}
 	GAS_HIP(c, gas_launch_mix_reduce(c->stream, parts, p_total, c->partial_rows, 1, F, d_out));
@@ -914,6 +924,9 @@ int apply_pending_frees(gas_ctx *c) {
 
 // HRTF sources take the frequency-domain path unless their peak is needed.
 inline int launch_group(const gas_ctx *c, const SlotInfo &si) {
+	if (c->force_staged && si.kind == GAS_KIND_EFFECT && si.chain_sig != 0) {
+		return G_FX_GENERIC;
+	}
 	const bool want_peak = wants_peak(c, si);
 	if (si.group == G_FX_HRTF && want_peak && !uni_ok(c)) {
 		return G_FX_HRTF_PK;
@@ -1355,7 +1368,7 @@ int gas_source_alloc(gas_ctx *c, int kind, const int32_t *effects, uint32_t n_ef
 	if (g == -2) {
 		return GAS_ERR_UNSUPPORTED_CHAIN;
 	}
-	const uint16_t sig = g == G_FX_GENERIC ? chain_signature(effects, n_effects) : 0;
+	const uint16_t sig = (g == G_FX_GENERIC || (kind == GAS_KIND_EFFECT && n_effects > 0)) ? chain_signature(effects, n_effects) : 0; // fused chains keep theirs too: a bus callback runs them staged
 	if ((g == G_FX_ER || g == G_FX_ER_HRTF || (g == G_FX_GENERIC && chain_has(sig, GAS_FX_EARLY_REFLECTIONS))) && c->cfg.er_ring_frames == 0) {
 		return GAS_ERR_UNSUPPORTED_CHAIN;
 	}
@@ -2172,16 +2185,33 @@ int gas_process_block_buses(gas_ctx *c, const gas_audio_frame *src, const uint32
 		return fail(rc);
 	}
 	apply_pending_frees(c);
+	// Two forms: every source GAS_KIND_3D_MIX (the mix-channel buses of AudioSpatializer3D, fused in the biquad
+	// kernels), or every source an effect chain (run staged: per-source rows, then mixed per bus) on a one-pair context.
+	bool all_mix = true, all_fx = n > 0;
+	for (uint32_t i = 0; i < n && slots; i++) {
+		if (slots[i] < c->cfg.max_sources && c->slots[slots[i]].used) {
+			const SlotInfo &si = c->slots[slots[i]];
+			all_mix = all_mix && si.kind == GAS_KIND_3D_MIX;
+			all_fx = all_fx && si.kind == GAS_KIND_EFFECT && si.chain_sig != 0;
+		}
+	}
+	const bool staged = !all_mix && all_fx && C == 1;
+	c->force_staged = staged;
 	rc = build_groups(c, slots, n);
+	c->force_staged = false;
+	c->cached_n = staged ? UINT32_MAX : c->cached_n; // the staged grouping is this call's only: a later list reuse must regroup
 	if (rc != GAS_OK) {
 		c->cached_n = UINT32_MAX;
 		return fail(rc);
 	}
 	for (int gt = 0; gt < G_COUNT; gt++) {
-		if (gt != G_3D_MIX && c->groups[gt].count > 0) {
+		if (gt != (staged ? G_FX_GENERIC : G_3D_MIX) && c->groups[gt].count > 0) {
 			c->cached_n = UINT32_MAX;
-			return fail(GAS_ERR_UNSUPPORTED_CHAIN); // bus routing restates AudioSpatializer3D's mix-channel buses only
+			return fail(GAS_ERR_UNSUPPORTED_CHAIN);
 		}
+	}
+	if (staged && needs_hrtf(c)) {
+		return fail(GAS_ERR_NO_HRTF);
 	}
 	rc = join_outputs(c);
 	if (rc == GAS_OK) {
@@ -2241,7 +2271,19 @@ int gas_process_block_buses(gas_ctx *c, const gas_audio_frame *src, const uint32
 			d_out = c->d_bus_out;
 			d_peaks = c->d_peaks;
 		}
-		if (n > 0) {
+		if (staged) {
+			// effect kinds: the stages of every chain with rows out, then k_rows_accumulate_buses and one reduce over the
+			// buses (run_groups' staged-chain path, told about the buses)
+			gas_bus_args ba;
+			ba.routes = c->d_routes;
+			ba.n_buses = n_buses;
+			c->run_buses = &ba;
+			const int rcg = run_groups(c, d_src, c->d_slots, c->cached_identity_rows ? nullptr : c->d_rows, c->groups, c->chain_ranges, n, d_out, d_peaks, 0, 1, -1, false, false);
+			c->run_buses = nullptr;
+			if (rcg != GAS_OK) {
+				return rcg;
+			}
+		} else if (n > 0) {
 			GAS_HIP(c, hipMemsetAsync(d_peaks, 0, (size_t)n * 2 * sizeof(float), c->stream)); // k_biquad_mix accumulates peaks over channel pairs
 			gas_group_args ga;
 			ga.src = d_src;
@@ -2256,7 +2298,9 @@ int gas_process_block_buses(gas_ctx *c, const gas_audio_frame *src, const uint32
 			// force the multi-bus code even for one bus when the caller routes (a lone bus other than 0 is legal)
 			GAS_HIP(c, gas_launch_biquad_mix(c->stream, GAS_MODE_MIX_CHANNEL, ga, c->st, F, 0, C, c->cfg.mix_rate, c->d_bus_partials, 0, P, nullptr, ba));
 		}
-		GAS_HIP(c, gas_launch_mix_reduce(c->stream, c->d_bus_partials, P, P ? P : 1, n_buses * C, F, d_out));
+		if (!staged) {
+			GAS_HIP(c, gas_launch_mix_reduce(c->stream, c->d_bus_partials, P, P ? P : 1, n_buses * C, F, d_out));
+		}
 		if (mem == GAS_MEM_HOST) {
 			GAS_HIP(c, hipMemcpyAsync(out, c->d_bus_out, out_bytes, hipMemcpyDeviceToHost, c->stream));
 			if (peaks && n > 0) {

@@ -136,6 +136,7 @@ hipError_t gas_launch_er_only(hipStream_t stream, const gas_group_args &g, const
 // stages of a general effect chain (rows in -> rows out) and its final mix
 hipError_t gas_launch_hrtf_rows(hipStream_t stream, bool crossfade, const gas_group_args &g, const gas_dev_state &st, const gas_hrtf_table &tab, const float2 *twiddles, uint32_t frames, gas_audio_frame *rows_out);
 hipError_t gas_launch_rows_accumulate(hipStream_t stream, const gas_group_args &g, uint32_t frames, float *partials, uint32_t p_offset);
+hipError_t gas_launch_rows_accumulate_buses(hipStream_t stream, const gas_group_args &g, uint32_t frames, const gas_bus_route *routes, uint32_t n_buses, uint32_t bus_rows, float *partials, uint32_t p_offset); // bus b's partial rows: [b * bus_rows + p_offset + workgroup]
 
 hipError_t gas_launch_hrtf_table(hipStream_t stream, const float *d_hrir, uint32_t dirs, uint32_t taps, const float2 *twiddles, float4 *spec);
 void gas_make_twiddles(float2 *host_tw /* [64][16] */);

@@ -733,6 +733,82 @@ __global__ __launch_bounds__(WAVES * 64) void k_rows_accumulate(gas_group_args g
 	}
 }
 
+// The same for several output buses (effect kinds): every source's rows are added into each bus with
+// that source's weight there -- 1 on its dry bus, its send volume on its send bus (audio_spatializer.cpp:274-324 gives
+// the volumes, AudioServer the per-bus multiply-accumulate); the peak is that of the rows, before any bus factor.
+// Partial rows of bus b: [b * bus_rows + p_offset + workgroup].  Buses beyond n_buses cost nothing (their weights are 0
+// and their stores are skipped).
+template <int FQ>
+__global__ __launch_bounds__(WAVES * 64) void k_rows_accumulate_buses(gas_group_args g, const gas_bus_route *__restrict__ routes, uint32_t n_buses, uint32_t bus_rows, float *__restrict__ partials, uint32_t p_offset) {
+	constexpr uint32_t F = FQ * 64;
+	constexpr int NB = GAS_MAX_BUSES;
+	__shared__ float red_all[WAVES * F * 2];
+	const int lane = threadIdx.x & 63;
+	const int wave = threadIdx.x >> 6;
+	float accL[NB][FQ], accR[NB][FQ];
+#pragma unroll
+	for (int b = 0; b < NB; b++) {
+#pragma unroll
+		for (int t = 0; t < FQ; t++) {
+			accL[b][t] = 0.0f;
+			accR[b][t] = 0.0f;
+		}
+	}
+	uint32_t first, last;
+	wave_range(g.n, blockIdx.x * WAVES + wave, gridDim.x * WAVES, first, last);
+	for (uint32_t e = first; e < last; e++) {
+		const uint32_t row = g.rows ? g.rows[e] : e; // where this source's peak goes
+		const gas_bus_route r = routes[g.slots[e]]; // wave-uniform
+		gas_audio_frame fr[FQ];
+		float pkl = 0.0f, pkr = 0.0f;
+#pragma unroll
+		for (int q = 0; q < FQ; q++) {
+			fr[q] = g.src[(size_t)e * F + lane + 64 * q]; // dense rows of the previous stage
+			pkl = fmaxf(pkl, fabsf(fr[q].left));
+			pkr = fmaxf(pkr, fabsf(fr[q].right));
+		}
+#pragma unroll
+		for (int b = 0; b < NB; b++) {
+			const float wl = (r.dry_bus == (uint32_t)b ? 1.0f : 0.0f) + (r.send_bus == (uint32_t)b ? r.send[0][0] : 0.0f);
+			const float wr = (r.dry_bus == (uint32_t)b ? 1.0f : 0.0f) + (r.send_bus == (uint32_t)b ? r.send[0][1] : 0.0f);
+			if ((uint32_t)b < n_buses && (wl != 0.0f || wr != 0.0f)) { // wave-uniform
+#pragma unroll
+				for (int q = 0; q < FQ; q++) {
+					accL[b][q] += fr[q].left * wl;
+					accR[b][q] += fr[q].right * wr;
+				}
+			}
+		}
+		pkl = wave_max(pkl);
+		pkr = wave_max(pkr);
+		if (lane == 0) {
+			g.peaks[(size_t)row * 2] = pkl;
+			g.peaks[(size_t)row * 2 + 1] = pkr;
+		}
+	}
+	float *red = red_all + wave * F * 2;
+#pragma unroll
+	for (int b = 0; b < NB; b++) {
+		if ((uint32_t)b < n_buses) { // uniform over the launch
+#pragma unroll
+			for (int t = 0; t < FQ; t++) {
+				*reinterpret_cast<float2 *>(red + (lane + 64 * t) * 2) = make_float2(accL[b][t], accR[b][t]);
+			}
+			__syncthreads();
+			float *my_partial = partials + ((size_t)b * bus_rows + p_offset + blockIdx.x) * (F * 2);
+			for (int idx = threadIdx.x; idx < (int)(F * 2); idx += WAVES * 64) {
+				float sacc = 0.0f;
+#pragma unroll
+				for (int w = 0; w < WAVES; w++) {
+					sacc += red_all[w * F * 2 + idx];
+				}
+				my_partial[idx] = sacc;
+			}
+			__syncthreads();
+		}
+	}
+}
+
 // HRIR [dirs][2][taps] -> lane-major half-spectra table (see issue_spectra), one wave per (direction, ear),
 // scaled by 1/512 so the inverse transform needs no normalisation.
 __global__ __launch_bounds__(64) void k_hrtf_table(const float *__restrict__ hrir, uint32_t dirs, uint32_t taps, const float2 *__restrict__ tw, float4 *__restrict__ spec) {
@@ -1020,6 +1096,34 @@ hipError_t gas_launch_rows_accumulate(hipStream_t stream, const gas_group_args &
 			break;
 		case 8:
 			hipLaunchKernelGGL((k_rows_accumulate<8>), grid, block, 0, stream, g, partials, p_offset);
+			break;
+		default:
+			return hipErrorInvalidValue;
+	}
+	return hipGetLastError();
+}
+
+hipError_t gas_launch_rows_accumulate_buses(hipStream_t stream, const gas_group_args &g, uint32_t frames, const gas_bus_route *routes, uint32_t n_buses, uint32_t bus_rows, float *partials, uint32_t p_offset) {
+	if (g.n == 0) {
+		return hipSuccess;
+	}
+	if (!g.slots || !routes || n_buses == 0 || n_buses > GAS_MAX_BUSES) {
+		return hipErrorInvalidValue;
+	}
+	const uint32_t wgs = gas_hrtf_partials(g.n);
+	dim3 grid(wgs), block(WAVES * 64);
+	switch (frames / 64) {
+		case 2:
+			hipLaunchKernelGGL((k_rows_accumulate_buses<2>), grid, block, 0, stream, g, routes, n_buses, bus_rows, partials, p_offset);
+			break;
+		case 4:
+			hipLaunchKernelGGL((k_rows_accumulate_buses<4>), grid, block, 0, stream, g, routes, n_buses, bus_rows, partials, p_offset);
+			break;
+		case 6:
+			hipLaunchKernelGGL((k_rows_accumulate_buses<6>), grid, block, 0, stream, g, routes, n_buses, bus_rows, partials, p_offset);
+			break;
+		case 8:
+			hipLaunchKernelGGL((k_rows_accumulate_buses<8>), grid, block, 0, stream, g, routes, n_buses, bus_rows, partials, p_offset);
 			break;
 		default:
 			return hipErrorInvalidValue;

@@ -108,3 +108,83 @@ def test_buses_reject_other_kinds_and_bad_counts(gas):
         assert ei.value.status == -1
         out, _ = ctx.process_block_buses(np.zeros((0, 512, 2), np.float32), [], 3)
         assert out.shape == (3, 1, 512, 2) and not out.any()
+
+
+@pytest.mark.parametrize("chain_name,n,n_buses,F", [("hrtf", 150, 2, 512), ("er_hrtf", 90, 3, 256), ("shelf", 64, 2, 512), ("shelf_hrtf", 70, 6, 512), ("hrtf", 2100, 2, 512)])
+def test_effect_kinds_route_to_buses(gas, ob, chain_name, n, n_buses, F):
+    """Effect chains (the HRTF spatializer's dry bus + reverb send): run staged, rows mixed per bus.  Expectation: each
+    source's own output from a one-source oracle, times its weight on each bus, summed in f32 products like AudioServer."""
+    from godot_audio_spatializer_amd import synth
+
+    K = gas.capi
+    HS, ER, HRTF = K.FX_HIGHSHELF, K.FX_EARLY_REFLECTIONS, K.FX_HRTF
+    chain = {"hrtf": (HRTF,), "er_hrtf": (ER, HRTF), "shelf": (HS,), "shelf_hrtf": (HS, HRTF)}[chain_name]
+    ring = 2048 if ER in chain else 0
+    dirs = 24
+    rng = np.random.default_rng(n + n_buses)
+    hrir = synth.synthetic_hrir(np.random.default_rng(7), dirs=dirs)
+    with gas.SpatializerContext(max_sources=n, frames=F, er_ring_frames=ring) as ctx:
+        ctx.hrtf_load(hrir)
+        slots = ctx.source_alloc_many(n, K.KIND_EFFECT, chain)
+        per_source = n <= 200
+        oracles = [ob.BatchOracle(ob.KIND_EFFECT, 1, F, chain=list(chain), hrir=hrir, er_ring_frames=max(ring, 1)) for _ in range(n)] if per_source else None
+        whole = ob.BatchOracle(ob.KIND_EFFECT, n, F, chain=list(chain), hrir=hrir, er_ring_frames=max(ring, 1))
+        for cb in range(3):
+            p = synth.draw_params(rng, n, dirs=dirs, ring_frames=max(ring, 2 * F), frames=F)
+            routes = np.zeros(n, K.BUS_ROUTE_DTYPE)
+            routes["dry_bus"] = rng.integers(0, n_buses, n)
+            routes["send_bus"] = np.where(rng.uniform(size=n) < 0.6, rng.integers(0, n_buses, n), K.BUS_NONE)
+            routes["send"][:, 0, :] = rng.uniform(0.0, 1.2, (n, 2)).astype(np.float32)
+            ctx.params_publish_batch(slots, p)
+            ctx.bus_routes_publish(slots, routes)
+            src = synth.draw_sources(rng, n, F)
+            got, peaks = ctx.process_block_buses(src, slots, n_buses)
+            _, wpeaks, w64 = whole.block(p.astype(ob.PARAMS_DTYPE), src, want64=True)
+            np.testing.assert_allclose(peaks, wpeaks, rtol=3e-5, atol=1e-7)  # the gate sees y, not a bus
+            if not per_source:
+                assert np.isfinite(got).all()  # full size: peaks above; the per-bus sums are checked by the split test below
+                continue
+            want = np.zeros((n_buses, F, 2), np.float64)
+            for s_ in range(n):
+                _, _, y = oracles[s_].block(p[s_:s_ + 1].astype(ob.PARAMS_DTYPE), src[s_:s_ + 1], want64=True)
+                y32 = y[0].astype(np.float32)
+                want[routes["dry_bus"][s_]] += y32
+                if routes["send_bus"][s_] != K.BUS_NONE:
+                    want[routes["send_bus"][s_]] += (y32 * routes["send"][s_, 0][None, :]).astype(np.float32)
+            for b in range(n_buses):
+                if np.abs(want[b]).max() > 0:
+                    assert rel_rms(got[b, 0], want[b]) <= TOL, (cb, b)
+                else:
+                    assert not got[b, 0].any()
+
+
+def test_effect_buses_without_sends_sum_to_the_single_mix(gas):
+    from godot_audio_spatializer_amd import synth
+
+    K = gas.capi
+    n, F, dirs = 2600, 512, 32
+    rng = np.random.default_rng(8)
+    hrir = synth.synthetic_hrir(np.random.default_rng(7), dirs=dirs)
+    p = synth.draw_params(rng, n, dirs=dirs, frames=F)
+    src = synth.draw_sources(rng, n, F)
+    routes = np.zeros(n, K.BUS_ROUTE_DTYPE)
+    routes["dry_bus"] = rng.integers(0, 3, n)
+    routes["send_bus"] = K.BUS_NONE
+    outs = []
+    for buses in (True, False):
+        with gas.SpatializerContext(max_sources=n, frames=F) as ctx:
+            ctx.hrtf_load(hrir)
+            slots = ctx.source_alloc_many(n, K.KIND_EFFECT, (K.FX_HRTF,))
+            ctx.params_publish_batch(slots, p)
+            if buses:
+                ctx.bus_routes_publish(slots, routes)
+                got, pk = ctx.process_block_buses(src, slots, 3)
+                outs.append((got.astype(np.float64).sum(axis=0)[0], pk))
+                # the list is regrouped for the next ordinary callback (the staged grouping was the bus call's only)
+                mix2, _ = ctx.process_block(src, slots)
+                assert np.isfinite(mix2).all()
+            else:
+                mix, pk = ctx.process_block(src, slots)
+                outs.append((mix[0].astype(np.float64), pk))
+    assert rel_rms(outs[0][0], outs[1][0]) <= 2e-6
+    np.testing.assert_allclose(outs[0][1], outs[1][1], rtol=3e-5, atol=1e-7)
