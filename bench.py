@@ -322,7 +322,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-max-sources", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the ordered / exact-peaks / latency / copy-ceiling / max-sources passes (profiling runs)")
-    ap.add_argument("--marked-callbacks", type=int, default=320, help="callbacks of the separate pass that brackets the dominant launch with HIP events (0 = none: roofline fields empty)")
+    ap.add_argument("--marked-callbacks", type=int, default=640, help="callbacks of the separate pass that brackets the dominant launch with HIP events (0 = none: roofline fields empty)")
     ap.add_argument("--reduce-bucket", type=int, default=32, help="callbacks per cross-GPU reduce (N > 1); 1 = every callback's mix is reduced on its own (real-time arrangement)")
     ap.add_argument("--crossfade", action="store_true", help="GAS_FLAG_HRTF_CROSSFADE: blend old/new HRIRs when a source's direction changes (SURVEY 8f#4)")
     ap.add_argument("--no-pipelined-mix", action="store_true", help="headline without GAS_FLAG_PIPELINED_MIX: the partial-mix sum of callback t runs before callback t+1's DSP kernel instead of under it")
