@@ -1515,7 +1515,7 @@ int gas_params_publish_batch(gas_ctx *c, const uint32_t *slots, const gas_params
 			return GAS_ERR_INVALID_ARGUMENT;
 		}
 		// Deferred: the next gas_process_block over this same list consumes the rows in its own launch when it can
-		// (all sources plain HRTF), else scatters them first.  The buffer must stay untouched until then.
+		// (all sources [HRTF] or [ER, HRTF] chains), else scatters them first.  The buffer must stay untouched until then.
 		if (c->pending_params) { // an earlier publish nobody consumed is about to be scattered: recorded callbacks first
 			const int rcd = flush_deferred(c);
 			if (rcd != GAS_OK) {
