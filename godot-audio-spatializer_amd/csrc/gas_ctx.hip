@@ -88,6 +88,8 @@ struct gas_ctx {
 	uint32_t deferred_n = 0;
 	uint64_t deferred_groups_gen = 0;
 	uint32_t batch_depth = 2; // callbacks per launch (gas_ctx_set_batch_depth), <= GAS_HRTF_MULTI_MAX_BLOCKS
+	int bus_form_cached = 0; // form of the last gas_process_block_buses whose list can be reused: 1 3D mix, 2 fused [HRTF], 0 none
+	uint64_t bus_form_groups_gen = 0;
 	bool force_staged = false; // gas_process_block_buses over effect kinds: every chain runs staged (rows out), the rows are mixed per bus
 	const gas_bus_args *run_buses = nullptr; // set for the duration of that run_groups
 	uint32_t partial_planes = 1; // planes of d_partials (1 ordered, 2 pipelined, 2 x max batch depth batched)
@@ -2157,7 +2159,12 @@ int gas_bus_routes_publish(gas_ctx *c, const uint32_t *slots, const gas_bus_rout
 // AudioSpatializer3D's buses in one launch: the mix_channel kernel with per-source weights per bus, its partial
 // planes summed by the ordinary deterministic reduce (bus-major: plane b * C + c).
 int gas_process_block_buses(gas_ctx *c, const gas_audio_frame *src, const uint32_t *slots, uint32_t n, uint32_t frames, gas_audio_frame *out, uint32_t n_buses, float *peaks, int mem) {
-	if (!c || !out || (mem != GAS_MEM_HOST && mem != GAS_MEM_DEVICE) || (n > 0 && (!src || !slots)) || n > c->cfg.max_sources || n_buses < 1 || n_buses > GAS_MAX_BUSES) {
+	// slots == NULL: the list (and grouping) of the previous call, like gas_process_block -- for the two forms whose
+	// grouping is the ordinary one (3D mix, fused [HRTF])
+	if (!c || !out || (mem != GAS_MEM_HOST && mem != GAS_MEM_DEVICE) || (n > 0 && !src) || n > c->cfg.max_sources || n_buses < 1 || n_buses > GAS_MAX_BUSES) {
+		return GAS_ERR_INVALID_ARGUMENT;
+	}
+	if (n > 0 && !slots && (c->cached_n != n || c->bus_form_cached == 0 || c->bus_form_groups_gen != c->groups_gen || !c->pending_free.empty())) {
 		return GAS_ERR_INVALID_ARGUMENT;
 	}
 	{ // GAS_FLAG_BATCHED_LAUNCH: callbacks waiting for their batch run first
@@ -2187,7 +2194,8 @@ int gas_process_block_buses(gas_ctx *c, const gas_audio_frame *src, const uint32
 	apply_pending_frees(c);
 	// Two forms: every source GAS_KIND_3D_MIX (the mix-channel buses of AudioSpatializer3D, fused in the biquad
 	// kernels), or every source an effect chain (run staged: per-source rows, then mixed per bus) on a one-pair context.
-	bool all_mix = true, all_fx = n > 0;
+	const bool reuse = n > 0 && !slots;
+	bool all_mix = reuse ? c->bus_form_cached == 1 : true, all_fx = reuse ? c->bus_form_cached == 2 : n > 0;
 	for (uint32_t i = 0; i < n && slots; i++) {
 		if (slots[i] < c->cfg.max_sources && c->slots[slots[i]].used) {
 			const SlotInfo &si = c->slots[slots[i]];
@@ -2195,22 +2203,37 @@ int gas_process_block_buses(gas_ctx *c, const gas_audio_frame *src, const uint32
 			all_fx = all_fx && si.kind == GAS_KIND_EFFECT && si.chain_sig != 0;
 		}
 	}
-	const bool staged = !all_mix && all_fx && C == 1;
-	c->force_staged = staged;
-	rc = build_groups(c, slots, n);
-	c->force_staged = false;
-	c->cached_n = staged ? UINT32_MAX : c->cached_n; // the staged grouping is this call's only: a later list reuse must regroup
-	if (rc != GAS_OK) {
-		c->cached_n = UINT32_MAX;
-		return fail(rc);
+	// [HRTF] sources onto one or two buses have a fused form (k_hrtf_uni<BUS2>: the second bus's spectra sums in LDS)
+	bool all_plain_hrtf = all_fx;
+	for (uint32_t i = 0; i < n && slots && all_plain_hrtf; i++) {
+		if (slots[i] < c->cfg.max_sources && c->slots[slots[i]].used) {
+			all_plain_hrtf = c->slots[slots[i]].group == G_FX_HRTF;
+		}
 	}
+	const bool fused_hrtf = !all_mix && all_plain_hrtf && C == 1 && n_buses <= 2 && uni_ok(c) && !c->fused_streams && gas_hrtf_uni_waves() == 8;
+	const bool staged = !all_mix && all_fx && C == 1 && !fused_hrtf;
+	if (reuse && (staged || (n_buses > 2 && all_fx))) {
+		return fail(GAS_ERR_INVALID_ARGUMENT); // the staged form regroups: it needs the list
+	}
+	if (!reuse) {
+		c->force_staged = staged;
+		rc = build_groups(c, slots, n);
+		c->force_staged = false;
+		c->cached_n = staged ? UINT32_MAX : c->cached_n; // the staged grouping is this call's only: a later list reuse must regroup
+		if (rc != GAS_OK) {
+			c->cached_n = UINT32_MAX;
+			return fail(rc);
+		}
+	}
+	c->bus_form_cached = staged ? 0 : (fused_hrtf ? 2 : (all_mix ? 1 : 0));
+	c->bus_form_groups_gen = c->groups_gen;
 	for (int gt = 0; gt < G_COUNT; gt++) {
-		if (gt != (staged ? G_FX_GENERIC : G_3D_MIX) && c->groups[gt].count > 0) {
+		if (gt != (staged ? G_FX_GENERIC : (fused_hrtf ? G_FX_HRTF : G_3D_MIX)) && c->groups[gt].count > 0) {
 			c->cached_n = UINT32_MAX;
 			return fail(GAS_ERR_UNSUPPORTED_CHAIN);
 		}
 	}
-	if (staged && needs_hrtf(c)) {
+	if ((staged || fused_hrtf) && needs_hrtf(c)) {
 		return fail(GAS_ERR_NO_HRTF);
 	}
 	rc = join_outputs(c);
@@ -2239,8 +2262,8 @@ int gas_process_block_buses(gas_ctx *c, const gas_audio_frame *src, const uint32
 			GAS_HIP(c, hipMemcpyAsync(c->d_routes, c->h_routes_pinned, sizeof(gas_bus_route) * c->cfg.max_sources, hipMemcpyHostToDevice, c->stream));
 			GAS_HIP(c, hipStreamSynchronize(c->stream)); // the pinned mirror is rewritten by the next snapshot
 		}
-		const uint32_t P = n ? gas_biquad_partials(n) : 0;
-		const size_t need = (size_t)n_buses * C * (P ? P : 1) * F * 2;
+		const uint32_t P = n ? (fused_hrtf ? gas_hrtf_uni_partials(n) : gas_biquad_partials(n)) : 0;
+		const size_t need = (size_t)(fused_hrtf && n_buses < 2 ? 2 : n_buses) * C * (P ? P : 1) * F * 2; // the fused [HRTF] form always writes two planes
 		if (need > c->bus_partial_floats) {
 			GAS_HIP(c, hipStreamSynchronize(c->stream));
 			(void)hipFree(c->d_bus_partials);
@@ -2271,7 +2294,22 @@ int gas_process_block_buses(gas_ctx *c, const gas_audio_frame *src, const uint32
 			d_out = c->d_bus_out;
 			d_peaks = c->d_peaks;
 		}
-		if (staged) {
+		if (fused_hrtf && n > 0) {
+			const Group &gr = c->groups[G_FX_HRTF];
+			gas_group_args ga;
+			ga.src = d_src;
+			ga.rows = c->cached_identity_rows ? nullptr : c->d_rows + gr.offset;
+			ga.slots = c->d_slots + gr.offset;
+			ga.slot_base = 0;
+			ga.n = n;
+			ga.peaks = d_peaks;
+			if (gr.contiguous) {
+				ga.slots = nullptr;
+				ga.slot_base = gr.slot_base;
+			}
+			// bus b's partial rows: [b * P, (b + 1) * P)
+			GAS_HIP(c, gas_launch_hrtf_uni(c->stream, ga, c->uni_peak_any && !c->uni_peak_all ? c->d_peak_bits : nullptr, c->uni_peak_all, c->st, c->tab, c->d_tw, F, c->hist_len, c->d_bus_partials, 0, nullptr, c->d_fade_env, nullptr, gas_deferred_reduce(), c->d_routes, P));
+		} else if (staged) {
 			// effect kinds: the stages of every chain with rows out, then k_rows_accumulate_buses and one reduce over the
 			// buses (run_groups' staged-chain path, told about the buses)
 			gas_bus_args ba;

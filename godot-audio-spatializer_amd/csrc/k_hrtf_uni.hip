@@ -69,8 +69,13 @@ struct UniLds {
 	static constexpr int TOTAL_F2 = EPI_F2 > LOOP_F2 ? EPI_F2 : LOOP_F2;
 };
 
-template <int SQ, bool SRC_PCM>
-__global__ __launch_bounds__(UW * 64, LEAN ? 3 : GAS_HRTF_WAVES_PER_SIMD) void k_hrtf_uni(gas_group_args g, const uint32_t *__restrict__ peak_bits, uint32_t peak_all, gas_dev_state st, gas_hrtf_table tab, const float2 *__restrict__ tw, float *__restrict__ partials, uint32_t p_offset, gas_cursor *__restrict__ cursors, const float *__restrict__ fade_env, const gas_params *__restrict__ fresh, gas_deferred_reduce job) {
+// BUS2 (gas_process_block_buses with [HRTF] sources and one or two buses): every source's output goes to
+// bus b with weight w_b = (dry_bus == b) + (send_bus == b ? send : 0) per ear.  Bus 0 keeps the register sums (weighted),
+// bus 1's sums live in LDS (64 KB the plain form does not use) and are only touched by sources that reach it; the
+// epilogue runs once per bus.  Partial rows of bus b: [b * bus_rows + p_offset + workgroup].
+template <int SQ, bool SRC_PCM, bool BUS2 = false>
+__global__ __launch_bounds__(UW * 64, LEAN ? 3 : GAS_HRTF_WAVES_PER_SIMD) void k_hrtf_uni(gas_group_args g, const uint32_t *__restrict__ peak_bits, uint32_t peak_all, gas_dev_state st, gas_hrtf_table tab, const float2 *__restrict__ tw, float *__restrict__ partials, uint32_t p_offset, gas_cursor *__restrict__ cursors, const float *__restrict__ fade_env, const gas_params *__restrict__ fresh, gas_deferred_reduce job, const gas_bus_route *__restrict__ routes = nullptr, uint32_t bus_rows = 0) {
+	static_assert(!BUS2 || (!SRC_PCM && !LEAN), "the two-bus form exists for float rows at 2 waves per SIMD");
 	constexpr int FQ = 2 * SQ; // F / 64
 	constexpr int HQ = 8 - SQ; // hist_len / 64
 	constexpr int NQ = 8 + SQ; // (hist_len + F) / 64
@@ -79,6 +84,7 @@ __global__ __launch_bounds__(UW * 64, LEAN ? 3 : GAS_HRTF_WAVES_PER_SIMD) void k
 	constexpr int FD_F2 = UniLds<SQ>::FD_F2;
 	__shared__ float2 lds_all[UniLds<SQ>::TOTAL_F2];
 	__shared__ float2 tw_lds[1024];
+	__shared__ float2 bus1_all[BUS2 ? UW * 2 * 512 : 1]; // bus 1: [wave][ear][512], the layout of the epilogue's fd
 	const int lane = threadIdx.x & 63;
 	const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 	float2 *lds = lds_all + (LEAN ? FD_F2 : 0) + wave * (UNI_SLICES * LDS_F2_HALF);
@@ -134,6 +140,21 @@ __global__ __launch_bounds__(UW * 64, LEAN ? 3 : GAS_HRTF_WAVES_PER_SIMD) void k
 		}
 	}
 	uint32_t my_flag = 0; // this lane's source needs its exact peak
+	float my_w0l = 1.0f, my_w0r = 1.0f, my_w1l = 0.0f, my_w1r = 0.0f; // BUS2: this lane's source on bus 0 / bus 1, per ear
+	if constexpr (BUS2) {
+		if (have) {
+			const gas_bus_route r = routes[lm.slot];
+			my_w0l = (r.dry_bus == 0u ? 1.0f : 0.0f) + (r.send_bus == 0u ? r.send[0][0] : 0.0f);
+			my_w0r = (r.dry_bus == 0u ? 1.0f : 0.0f) + (r.send_bus == 0u ? r.send[0][1] : 0.0f);
+			my_w1l = (r.dry_bus == 1u ? 1.0f : 0.0f) + (r.send_bus == 1u ? r.send[0][0] : 0.0f);
+			my_w1r = (r.dry_bus == 1u ? 1.0f : 0.0f) + (r.send_bus == 1u ? r.send[0][1] : 0.0f);
+		}
+#pragma unroll
+		for (int j = 0; j < 8; j++) {
+			bus1_all[(wave * 2 + 0) * 512 + j * 64 + lane] = make_float2(0.0f, 0.0f);
+			bus1_all[(wave * 2 + 1) * 512 + j * 64 + lane] = make_float2(0.0f, 0.0f);
+		}
+	}
 	if (have) {
 		const gas_params *P = fresh ? fresh + lm.row : st.params + lm.slot;
 		const float2 gd = *reinterpret_cast<const float2 *>(&P->hrtf_gain); // hrtf_gain, hrtf_dir: one 8-byte load
@@ -204,6 +225,7 @@ __global__ __launch_bounds__(UW * 64, LEAN ? 3 : GAS_HRTF_WAVES_PER_SIMD) void k
 	}
 	bool have_prev = false; // wave-uniform
 	uint32_t prev_flag = 0, prev_row = 0;
+	float pw0l = 1.0f, pw0r = 1.0f, pw1l = 0.0f, pw1r = 0.0f; // BUS2: the previous source's bus weights (wave-uniform)
 	if constexpr (LEAN) {
 #pragma unroll
 		for (int j = 0; j < 8; j++) {
@@ -255,7 +277,28 @@ __global__ __launch_bounds__(UW * 64, LEAN ? 3 : GAS_HRTF_WAVES_PER_SIMD) void k
 	// products of the previous source (zp x hs), its exact peak if asked for, then the request for `next_dir`'s row
 	auto products = [&](bool more, uint32_t next_dir) {
 		float2 yl[8], yr[8];
-		if (have_prev) {
+		if (have_prev && BUS2) {
+			finish_spectra(lane, hs);
+			float2 *b1 = bus1_all + wave * 2 * 512;
+			const bool to1 = pw1l != 0.0f || pw1r != 0.0f; // wave-uniform
+#pragma unroll
+			for (int j = 0; j < 8; j++) {
+				yl[j] = cmul_fixed(zp[j], hs[j].x, hs[j].y);
+				yr[j] = cmul_fixed(zp[j], hs[j].z, hs[j].w);
+				aYL[j] = make_float2(__builtin_fmaf(pw0l, yl[j].x, aYL[j].x), __builtin_fmaf(pw0l, yl[j].y, aYL[j].y));
+				aYR[j] = make_float2(__builtin_fmaf(pw0r, yr[j].x, aYR[j].x), __builtin_fmaf(pw0r, yr[j].y, aYR[j].y));
+			}
+			if (to1) {
+#pragma unroll
+				for (int j = 0; j < 8; j++) {
+					float2 a = b1[j * 64 + lane], b = b1[512 + j * 64 + lane];
+					a = make_float2(__builtin_fmaf(pw1l, yl[j].x, a.x), __builtin_fmaf(pw1l, yl[j].y, a.y));
+					b = make_float2(__builtin_fmaf(pw1r, yr[j].x, b.x), __builtin_fmaf(pw1r, yr[j].y, b.y));
+					b1[j * 64 + lane] = a;
+					b1[512 + j * 64 + lane] = b;
+				}
+			}
+		} else if (have_prev) {
 			finish_spectra(lane, hs);
 #pragma unroll
 			for (int j = 0; j < 8; j++) {
@@ -395,6 +438,13 @@ __global__ __launch_bounds__(UW * 64, LEAN ? 3 : GAS_HRTF_WAVES_PER_SIMD) void k
 			have_prev = true;
 			prev_flag = flag;
 			prev_row = m.row;
+			if constexpr (BUS2) {
+				const int i = (int)(e - first);
+				pw0l = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_w0l), i));
+				pw0r = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_w0r), i));
+				pw1l = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_w1l), i));
+				pw1r = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_w1r), i));
+			}
 		}
 	}
 	GAS_UNI_STAMP(3);
@@ -476,6 +526,35 @@ __global__ __launch_bounds__(UW * 64, LEAN ? 3 : GAS_HRTF_WAVES_PER_SIMD) void k
 	for (int idx = threadIdx.x; idx < (int)(F * 2); idx += UW * 64) {
 		my_partial[idx] = outp[idx];
 	}
+	if constexpr (BUS2) { // the same once more for bus 1, whose spectra have been in LDS all along
+		__syncthreads(); // outp has been read
+		if (wave < 2) {
+			float2 y[8];
+#pragma unroll
+			for (int j = 0; j < 8; j++) {
+				y[j] = bus1_all[wave * 512 + j * 64 + lane];
+			}
+#pragma unroll
+			for (int w = 1; w < UW; w++) {
+#pragma unroll
+				for (int j = 0; j < 8; j++) {
+					y[j] = cadd(y[j], bus1_all[(w * 2 + wave) * 512 + j * 64 + lane]);
+				}
+			}
+			inv(y, lds_all + FD_F2 + wave * LDS_F2_HALF);
+#pragma unroll
+			for (int t = 0; t < SQ; t++) {
+				const int fa = lane + 64 * t, fb = lane + 64 * (SQ + t);
+				outp[fa * 2 + wave] = y[HQ + t].x;
+				outp[fb * 2 + wave] = y[HQ + t].y;
+			}
+		}
+		__syncthreads();
+		float *bus1_partial = my_partial + (size_t)bus_rows * (size_t)(F * 2);
+		for (int idx = threadIdx.x; idx < (int)(F * 2); idx += UW * 64) {
+			bus1_partial[idx] = outp[idx];
+		}
+	}
 	GAS_UNI_STAMP(5);
 #ifdef GAS_STAMPS
 	if (lane == 0 && (blockIdx.x * UW + wave) < 8192) {
@@ -498,9 +577,33 @@ uint32_t gas_hrtf_uni_partials(uint32_t n) {
 	return w > need ? w : need;
 }
 
-hipError_t gas_launch_hrtf_uni(hipStream_t stream, const gas_group_args &g, const uint32_t *peak_bits, bool peak_all, const gas_dev_state &st, const gas_hrtf_table &tab, const float2 *twiddles, uint32_t frames, uint32_t hist_len, float *partials, uint32_t p_offset, gas_cursor *cursors, const float *fade_env, const gas_params *fresh, const gas_deferred_reduce &job) {
+hipError_t gas_launch_hrtf_uni(hipStream_t stream, const gas_group_args &g, const uint32_t *peak_bits, bool peak_all, const gas_dev_state &st, const gas_hrtf_table &tab, const float2 *twiddles, uint32_t frames, uint32_t hist_len, float *partials, uint32_t p_offset, gas_cursor *cursors, const float *fade_env, const gas_params *fresh, const gas_deferred_reduce &job, const gas_bus_route *routes, uint32_t bus_rows) {
 	if (g.n == 0) {
 		return hipSuccess;
+	}
+	if (routes) { // the two-bus form (gas_process_block_buses over [HRTF] sources)
+		if (LEAN || cursors || g.order || frames % 128 != 0 || frames > 512 || hist_len != 512 - frames / 2) {
+			return hipErrorInvalidValue;
+		}
+		const uint32_t bwgs = gas_hrtf_uni_partials(g.n);
+		const uint32_t ball = peak_all ? 1u : 0u;
+		if constexpr (!LEAN) {
+			switch (frames / 128) {
+				case 1:
+					hipLaunchKernelGGL((k_hrtf_uni<1, false, true>), dim3(bwgs), dim3(UW * 64), 0, stream, g, peak_bits, ball, st, tab, twiddles, partials, p_offset, cursors, fade_env, fresh, job, routes, bus_rows);
+					break;
+				case 2:
+					hipLaunchKernelGGL((k_hrtf_uni<2, false, true>), dim3(bwgs), dim3(UW * 64), 0, stream, g, peak_bits, ball, st, tab, twiddles, partials, p_offset, cursors, fade_env, fresh, job, routes, bus_rows);
+					break;
+				case 3:
+					hipLaunchKernelGGL((k_hrtf_uni<3, false, true>), dim3(bwgs), dim3(UW * 64), 0, stream, g, peak_bits, ball, st, tab, twiddles, partials, p_offset, cursors, fade_env, fresh, job, routes, bus_rows);
+					break;
+				default:
+					hipLaunchKernelGGL((k_hrtf_uni<4, false, true>), dim3(bwgs), dim3(UW * 64), 0, stream, g, peak_bits, ball, st, tab, twiddles, partials, p_offset, cursors, fade_env, fresh, job, routes, bus_rows);
+					break;
+			}
+		}
+		return hipGetLastError();
 	}
 	if (frames % 128 != 0 || frames > 512 || hist_len != 512 - frames / 2) {
 		return hipErrorInvalidValue;
@@ -511,9 +614,9 @@ hipError_t gas_launch_hrtf_uni(hipStream_t stream, const gas_group_args &g, cons
 #define GAS_UNI_CASE(SQv)                                                                                                                                                     \
 	case SQv:                                                                                                                                                                  \
 		if (cursors) {                                                                                                                                                         \
-			hipLaunchKernelGGL((k_hrtf_uni<SQv, true>), grid, block, 0, stream, g, peak_bits, all, st, tab, twiddles, partials, p_offset, cursors, fade_env, fresh, job);     \
+			hipLaunchKernelGGL((k_hrtf_uni<SQv, true>), grid, block, 0, stream, g, peak_bits, all, st, tab, twiddles, partials, p_offset, cursors, fade_env, fresh, job, (const gas_bus_route *)nullptr, 0u);     \
 		} else {                                                                                                                                                               \
-			hipLaunchKernelGGL((k_hrtf_uni<SQv, false>), grid, block, 0, stream, g, peak_bits, all, st, tab, twiddles, partials, p_offset, cursors, fade_env, fresh, job);    \
+			hipLaunchKernelGGL((k_hrtf_uni<SQv, false>), grid, block, 0, stream, g, peak_bits, all, st, tab, twiddles, partials, p_offset, cursors, fade_env, fresh, job, (const gas_bus_route *)nullptr, 0u);    \
 		}                                                                                                                                                                      \
 		break;
 	switch (frames / 128) {
