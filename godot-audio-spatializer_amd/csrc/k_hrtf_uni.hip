@@ -317,7 +317,10 @@ __global__ __launch_bounds__(UW * 64, LEAN ? 3 : GAS_HRTF_WAVES_PER_SIMD) void k
 			issue_spectra(tab.spec, next_dir, lane, hs);
 		}
 		if (have_prev && prev_flag) { // wave-uniform: this source's own output, for max |L|, max |R| (:436-443)
-			if constexpr (!LEAN) {
+			if constexpr (!LEAN && SRC_PCM) { // the stream-sampling form has no registers for the interleaved pair (same operations, same bits)
+				fft512<true>(yl, t1, t2, lds, lane);
+				fft512<true>(yr, t1, t2, lds + LDS_F2_HALF, lane);
+			} else if constexpr (!LEAN) {
 				fft512_pair<true>(yl, yr, t1, t2, lds, lds + LDS_F2_HALF, lane);
 			}
 			float pkl = 0.0f, pkr = 0.0f;
