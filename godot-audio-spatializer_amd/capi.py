@@ -166,6 +166,7 @@ EXPORTS = [
     "gas_bandwidth_probe",
     "gas_ctx_set_batch_depth",
     "gas_ctx_read_hrtf_order",
+    "gas_tune_uni12_min",
 ]
 
 
@@ -240,6 +241,8 @@ def load_library():
     L.gas_profile_read.argtypes = [vp, C.POINTER(Profile), i32]
     L.gas_bandwidth_probe.argtypes = [vp, C.c_uint64, C.c_uint64, u32, u32, u32, C.POINTER(C.c_double)]
     L.gas_ctx_read_hrtf_order.argtypes = [vp, vp, u32]
+    L.gas_tune_uni12_min.argtypes = [u32]
+    L.gas_tune_uni12_min.restype = u32
     L.gas_ctx_set_batch_depth.argtypes = [vp, u32]
     _lib = L
     return L

@@ -1230,13 +1230,15 @@ int gas_ctx_create(const gas_config *cfg, gas_ctx **out_ctx) {
 		GAS_HIP(c, hipMalloc(&c->d_stream_inc, sizeof(uint32_t) * N));
 		GAS_HIP(c, hipHostMalloc(&c->h_stream_inc, sizeof(uint32_t) * N, hipHostMallocDefault));
 		{
-			// the reference's fade-out envelope, same f32 recurrence (audio_spatializer.cpp:382-392)
-			float env[GAS_LOOKAHEAD_BUFFER_SIZE];
-			float fadeout_base = 0.96f, fadeout_coefficient = 1, buffer_size_float = (float)GAS_LOOKAHEAD_BUFFER_SIZE, buffer_linear_fade_idx = 0.0f;
-			for (int j = 0; j < GAS_LOOKAHEAD_BUFFER_SIZE; j++) {
-				fadeout_coefficient *= fadeout_base;
-				env[j] = fadeout_coefficient * (buffer_size_float - buffer_linear_fade_idx) / buffer_size_float;
-				buffer_linear_fade_idx += 1.0f;
+			// end-of-stream ramp the stream-sampling prologue multiplies the last 64 valid frames by: tap k =
+			// 0.96^(k+1) * (64 - k) / 64, the running f32 product and the f32 divide of audio_spatializer.cpp:382-392
+			// (the host layer builds the same table for its CPU windows)
+			constexpr int TAIL = GAS_LOOKAHEAD_BUFFER_SIZE;
+			float env[TAIL];
+			float decay = 1.0f;
+			for (int k = 0; k < TAIL; k++) {
+				decay *= 0.96f;
+				env[k] = decay * ((float)TAIL - (float)k) / (float)TAIL;
 			}
 			GAS_HIP(c, hipMalloc(&c->d_fade_env, sizeof(env)));
 			GAS_HIP(c, hipMemcpy(c->d_fade_env, env, sizeof(env), hipMemcpyHostToDevice));
@@ -2518,11 +2520,7 @@ int gas_bandwidth_probe(gas_ctx *c, uint64_t read_bytes, uint64_t write_bytes, u
 	// the read arena is swept in rotation so that successive launches cannot be served by the 256 MiB Infinity Cache
 	const size_t want_rd = read_bytes ? ((size_t)(320u << 20) / read_bytes + 2) * read_bytes : 16;
 	if (want_rd > c->probe_rd_bytes) {
-		(void)hipFree(c->d_routes);
-	(void)hipFree(c->d_bus_partials);
-	(void)hipFree(c->d_bus_out);
-	(void)hipHostFree(c->h_routes_pinned);
-	(void)hipFree(c->d_probe_rd);
+		(void)hipFree(c->d_probe_rd);
 		c->d_probe_rd = nullptr;
 		c->probe_rd_bytes = 0;
 		GAS_HIP(c, hipMalloc(&c->d_probe_rd, want_rd));

@@ -204,6 +204,118 @@ __device__ __forceinline__ void fft512_twlds(float2 (&v)[8], const float2 *tw, f
 	dft8<INV>(v);
 }
 
+// ---- LDS traffic the compiler does not see ---------------------------------------------------------------------------
+// While a global_load_lds (LDS-DMA) is in flight, hipcc puts `s_waitcnt vmcnt(0)` in front of every ds_read and ds_write
+// it emits (SIInsertWaitcnts cannot tell which LDS bytes the DMA writes, and with a store and loads pending on the one
+// vmcnt counter of gfx9 it does not count), which drains the wave's whole prefetch -- the next source's frames included
+// -- in the middle of the current transform.  The twelve-wave form of k_hrtf_uni therefore issues the LDS traffic of its
+// exchanges and the reads of its HRIR slots as inline assembly, each read group followed by its own lgkmcnt(0), and
+// orders the one true dependency (DMA -> slot read) itself with a vmcnt wait at the top of the trip.  A wave's DS
+// instructions execute in order, so reads placed after the exchange's writes see them without a wait in between.
+// The empty asm statements on the loaded scalars keep LLVM from re-vectorising the butterflies that follow into
+// v_pk_*_f32 (2.4x the issue cost of a scalar op on gfx950, profiles/r02_notes.md).
+typedef float gas_v2f __attribute__((ext_vector_type(2)));
+typedef float gas_v4f __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ uint32_t lds_byte_addr(const void *p) {
+	return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void *)p;
+}
+
+__device__ __forceinline__ float2 opaque_f2(gas_v2f r) {
+	float x = r.x, y = r.y;
+	asm volatile("" : "+v"(x), "+v"(y));
+	return make_float2(x, y);
+}
+
+// v[k] = *(float2 *)(addr + k * STRIDE), k = 0..7
+template <int STRIDE>
+__device__ __forceinline__ void lds_read8_b64(uint32_t addr, float2 (&v)[8]) {
+	gas_v2f r0, r1, r2, r3, r4, r5, r6, r7;
+	asm volatile("ds_read_b64 %0, %8 offset:%9\n\t"
+				 "ds_read_b64 %1, %8 offset:%10\n\t"
+				 "ds_read_b64 %2, %8 offset:%11\n\t"
+				 "ds_read_b64 %3, %8 offset:%12\n\t"
+				 "ds_read_b64 %4, %8 offset:%13\n\t"
+				 "ds_read_b64 %5, %8 offset:%14\n\t"
+				 "ds_read_b64 %6, %8 offset:%15\n\t"
+				 "ds_read_b64 %7, %8 offset:%16\n\t"
+				 "s_waitcnt lgkmcnt(0)"
+				 : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3), "=&v"(r4), "=&v"(r5), "=&v"(r6), "=&v"(r7)
+				 : "v"(addr), "n"(0 * STRIDE), "n"(1 * STRIDE), "n"(2 * STRIDE), "n"(3 * STRIDE), "n"(4 * STRIDE), "n"(5 * STRIDE), "n"(6 * STRIDE), "n"(7 * STRIDE)
+				 : "memory");
+	v[0] = opaque_f2(r0); v[1] = opaque_f2(r1); v[2] = opaque_f2(r2); v[3] = opaque_f2(r3);
+	v[4] = opaque_f2(r4); v[5] = opaque_f2(r5); v[6] = opaque_f2(r6); v[7] = opaque_f2(r7);
+}
+
+// *(float2 *)(addr + k * STRIDE) = v[k], k = 0..7
+template <int STRIDE>
+__device__ __forceinline__ void lds_write8_b64(uint32_t addr, const float2 (&v)[8]) {
+	const gas_v2f d0 = { v[0].x, v[0].y }, d1 = { v[1].x, v[1].y }, d2 = { v[2].x, v[2].y }, d3 = { v[3].x, v[3].y };
+	const gas_v2f d4 = { v[4].x, v[4].y }, d5 = { v[5].x, v[5].y }, d6 = { v[6].x, v[6].y }, d7 = { v[7].x, v[7].y };
+	asm volatile("ds_write_b64 %0, %1 offset:%9\n\t"
+				 "ds_write_b64 %0, %2 offset:%10\n\t"
+				 "ds_write_b64 %0, %3 offset:%11\n\t"
+				 "ds_write_b64 %0, %4 offset:%12\n\t"
+				 "ds_write_b64 %0, %5 offset:%13\n\t"
+				 "ds_write_b64 %0, %6 offset:%14\n\t"
+				 "ds_write_b64 %0, %7 offset:%15\n\t"
+				 "ds_write_b64 %0, %8 offset:%16"
+				 :
+				 : "v"(addr), "v"(d0), "v"(d1), "v"(d2), "v"(d3), "v"(d4), "v"(d5), "v"(d6), "v"(d7), "n"(0 * STRIDE), "n"(1 * STRIDE), "n"(2 * STRIDE), "n"(3 * STRIDE), "n"(4 * STRIDE), "n"(5 * STRIDE), "n"(6 * STRIDE), "n"(7 * STRIDE)
+				 : "memory");
+}
+
+// fft512 with its exchanges issued by lds_write8_b64 / lds_read8_b64 (same butterflies, same twiddles, same bits)
+template <bool INV>
+__device__ __forceinline__ void fft512_ar(float2 (&v)[8], const float2 (&t1)[8], const float2 (&t2)[8], float2 *lds, int lane) {
+	const int hi = lane >> 3, lo = lane & 7;
+	const uint32_t base = lds_byte_addr(lds);
+	dft8<INV>(v);
+#pragma unroll
+	for (int k = 1; k < 8; k++) {
+		v[k] = INV ? cmulc(v[k], t1[k]) : cmul(v[k], t1[k]);
+	}
+	lds_write8_b64<72 * 8>(base + (uint32_t)lane * 8u, v); // lds[k * 72 + lane] = v[k]
+	lds_read8_b64<64>(base + (uint32_t)(hi * 72 + lo) * 8u, v); // v[k] = lds[hi * 72 + k * 8 + lo]
+	dft8<INV>(v);
+#pragma unroll
+	for (int k = 0; k < 8; k++) {
+		v[k] = INV ? cmulc(v[k], t2[k]) : cmul(v[k], t2[k]);
+	}
+	lds_write8_b64<64>(base + (uint32_t)(lo * 66 + hi) * 8u, v); // lds[lo * 66 + k * 8 + hi] = v[k]
+	lds_read8_b64<66 * 8>(base + (uint32_t)lane * 8u, v); // v[k] = lds[k * 66 + lane]
+	dft8<INV>(v);
+}
+
+// H[lane + 64 j], j = 0..7, out of a 4 KiB LDS slot holding the stored half of one HRIR row (256 float4, bins 0..255,
+// Nyquist parked in DC's imaginary parts): bins < 256 as stored, bins >= 256 as conj(H[512 - k]) read backwards; lane 0
+// unpacks DC and Nyquist from entry 0 (finish_spectra's result, from LDS instead of registers).
+__device__ __forceinline__ void slot_read_spectra(const float4 *slot, int lane, float4 (&h)[8]) {
+	const uint32_t a = lds_byte_addr(slot) + (uint32_t)lane * 16u; // entries lane + 64 j, j < 4
+	const uint32_t m = lds_byte_addr(slot) + (uint32_t)(64 - lane) * 16u; // entries 64 - lane + 64 t: t = 0..3 <-> j = 7..4
+	const uint32_t m4 = lane == 0 ? lds_byte_addr(slot) : m + 3072u; // j = 4: entry 256 - lane; lane 0 (entry 256 = Nyquist) reads entry 0 again
+	gas_v4f r0, r1, r2, r3, r4, r5, r6, r7;
+	asm volatile("ds_read_b128 %0, %8\n\t"
+				 "ds_read_b128 %1, %8 offset:1024\n\t"
+				 "ds_read_b128 %2, %8 offset:2048\n\t"
+				 "ds_read_b128 %3, %8 offset:3072\n\t"
+				 "ds_read_b128 %4, %10\n\t"
+				 "ds_read_b128 %5, %9 offset:2048\n\t"
+				 "ds_read_b128 %6, %9 offset:1024\n\t"
+				 "ds_read_b128 %7, %9\n\t"
+				 "s_waitcnt lgkmcnt(0)"
+				 : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3), "=&v"(r4), "=&v"(r5), "=&v"(r6), "=&v"(r7)
+				 : "v"(a), "v"(m), "v"(m4)
+				 : "memory");
+	h[0] = make_float4(r0.x, r0.y, r0.z, r0.w); h[1] = make_float4(r1.x, r1.y, r1.z, r1.w); h[2] = make_float4(r2.x, r2.y, r2.z, r2.w); h[3] = make_float4(r3.x, r3.y, r3.z, r3.w);
+	h[4] = make_float4(r4.x, -r4.y, r4.z, -r4.w); h[5] = make_float4(r5.x, -r5.y, r5.z, -r5.w); h[6] = make_float4(r6.x, -r6.y, r6.z, -r6.w); h[7] = make_float4(r7.x, -r7.y, r7.z, -r7.w);
+	if (lane == 0) {
+		h[4] = make_float4(r0.y, 0.0f, r0.w, 0.0f);
+		h[0].y = 0.0f;
+		h[0].w = 0.0f;
+	}
+}
+
 // max over the wave of a NON-NEGATIVE value, on the VALU's DPP data path (no LDS round trips):
 // row_shr 1,2,4,8 leave each 16-lane row's max in its lane 15, row_bcast15 / row_bcast31 fold the
 // rows; zero fill is the identity for non-negative inputs.  Lane 63 holds the result.

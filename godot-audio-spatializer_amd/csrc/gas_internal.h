@@ -154,5 +154,6 @@ bool gas_dir_order_supported(uint32_t dirs);
 #define GAS_XCD_ORDER_AUTO_MIN 0xFFFFFFFFu // callbacks of at least this many sources are ordered without the flag: never (measured: no net gain at any size); the environment variable of the same name overrides for experiments
 hipError_t gas_launch_xcd_order(hipStream_t stream, const gas_group_args &g, const gas_params *params, const gas_params *fresh, uint32_t dirs, uint32_t hrtf_wgs, uint32_t waves_per_wg, uint32_t *order);
 uint32_t gas_hrtf_uni_waves();
+bool gas_hrtf_uni_twelve(uint32_t n, bool streams, bool buses); // whether a callback of n plain-[HRTF] sources runs k_hrtf_uni's twelve-wave form (its sums differ from the eight-wave form's in the last bits)
 hipError_t gas_launch_dir_order(hipStream_t stream, const gas_group_args &g, const gas_params *params, const gas_params *fresh, uint32_t dirs, uint32_t *order);
 hipError_t gas_launch_zero_slot(hipStream_t stream, const gas_dev_state &st, uint32_t slot, uint32_t hist_len, uint32_t er_ring_frames);

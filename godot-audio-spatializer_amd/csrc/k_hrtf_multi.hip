@@ -21,6 +21,9 @@
 // direction meets them again), and once-touched frames that do not displace them from the L2 are worth 4.5 % of the
 // launch (10.65 vs 11.15 us per block, profiles/r02_notes.md).  The single-block kernels show no difference.
 #define GAS_USE_NT 1
+#ifndef GAS_MULTI_L2_PREFETCH
+#define GAS_MULTI_L2_PREFETCH 1 // touch the rows of the source two trips ahead (one dword per 128-byte line)
+#endif
 #include "gas_hrtf_wave.h"
 
 namespace {
@@ -125,6 +128,7 @@ __global__ __launch_bounds__(MW * 64, GAS_HRTF_WAVES_PER_SIMD) void k_hrtf_multi
 		t2[k] = tw_lds[(8 + k) * 64 + lane];
 	}
 	const float lane_f = (float)lane;
+	uint32_t pf_word = 0; // GAS_MULTI_L2_PREFETCH: the word of the line touch in flight
 
 	for (uint32_t b = 0; b < K; b++) {
 		float *peaks_b = mb.peaks[b];
@@ -240,6 +244,23 @@ __global__ __launch_bounds__(MW * 64, GAS_HRTF_WAVES_PER_SIMD) void k_hrtf_multi
 			}
 			fft512<false>(zs, t1, t2, lds, lane);
 			products(true, dir);
+#if GAS_MULTI_L2_PREFETCH
+			// The row of the source TWO trips ahead is pulled towards the L2 by one dword load per 128-byte line (no
+			// landing set: the loaded word is never looked at), issued behind this trip's requests AND behind the
+			// table row's (the wave's vector-memory results return in order, and the compiler's wait in front of the spectral
+			// products is vmcnt(0): anything requested before them would be waited for there).  A trip's own requests then find their lines a cache hit
+			// away instead of an HBM round trip under load (the trip is latency-bound with one source in flight per wave,
+			// profiles/r03_notes.md).  The word requested a trip ago is retired first (it has landed long since).
+			{
+				asm volatile("" ::"v"(pf_word));
+				const uint32_t i2 = i + 2, over = i2 / cnt, ni2 = i2 - over * cnt; // cnt >= 1; over <= 2
+				if (b + over < K) {
+					const uint32_t row2 = (uint32_t)__builtin_amdgcn_readlane((int)my_row, (int)ni2);
+					const char *p2 = reinterpret_cast<const char *>(mb.src[b + over] + (size_t)row2 * F);
+					pf_word = *reinterpret_cast<const uint32_t *>(p2 + ((uint32_t)lane * 128u) % (F * 8u));
+				}
+			}
+#endif
 #pragma unroll
 			for (int j = 0; j < 8; j++) {
 				zp[j] = zs[j];

@@ -25,7 +25,13 @@
 //
 // Mapping (CDNA4, wave64), algorithm, LDS layout: gas_hrtf_wave.h / DESIGN.md 3.1.  Bound: HBM.  Algorithmic bytes
 // per source = F*8 (frames) + 2*hist_len*4 (history r+w) + 24 (gain, direction, previous gain r/w, peak).
+#include <cstdlib>
+
 #include "gas_hrtf_wave.h"
+
+#ifndef GAS_UNI12_DEFAULT_MIN
+#define GAS_UNI12_DEFAULT_MIN 0 // sources from which the twelve-wave form is the default (0 = only on request)
+#endif
 
 namespace {
 
@@ -40,32 +46,29 @@ namespace {
 #define GAS_UNI_STAMP(i) do { } while (0)
 #endif
 
-// UW = waves per workgroup (one workgroup per CU).  LEAN = register diet for a third wave per SIMD (<= 168 VGPRs):
-// twiddles read from LDS at their point of use, no product skew (the table row is requested before the transform
-// and used right after it), exact peaks by two inverse transforms in sequence through one exchange slice.
-#ifndef GAS_UNI_WAVES
-#define GAS_UNI_WAVES 8
-#endif
-constexpr int UW = GAS_UNI_WAVES;
-#ifndef GAS_UNI_DEPTH
-#define GAS_UNI_DEPTH 1 // sources whose frames + history are in flight per wave (landing register sets)
-#endif
-constexpr int UD = GAS_UNI_DEPTH;
-#ifndef GAS_UNI_UNIFORM_NEXT
-#define GAS_UNI_UNIFORM_NEXT 0 // 1: request the next source's data on EVERY trip of the source loop (exact vmcnt waits; measured 0.4 us slower, see there)
-#endif
-constexpr bool LEAN = UW > 8;
-constexpr int UNI_SLICES = LEAN ? 1 : 2; // exchange slices per wave in the source loop
+// UW = waves per workgroup (one workgroup per CU): 8 = two waves per SIMD, the general form (stream sampling, two buses);
+// 12 = three waves per SIMD (<= 168 VGPRs), float rows on one bus.  What the third wave costs in registers is paid by
+// the HRIR row: the twelve-wave form never holds it in VGPRs.  Each wave owns two 4 KiB LDS slots; the stored half
+// of the next source's row (256 float4) is copied global -> LDS by four global_load_lds_dwordx4 at the top of a trip
+// and read back one trip later, in natural order for bins < 256 and in mirrored order for bins >= 256 (the table's
+// Hermitian half, gas_hrtf_wave.h) -- half the L2 -> CU bytes of the register form, no 32-VGPR landing set, and no
+// skewed spectrum copy (the products follow the transform they belong to).  Same operations per source, but the
+// sources are split over 12 waves instead of 8, so the sums differ from the 8-wave form's in the last bits.
+template <int UW>
+struct UniCfg {
+	static constexpr bool LEAN = UW > 8;
+	static constexpr int SLICES = LEAN ? 1 : 2; // exchange slices per wave in the source loop
+	static constexpr int TSLOT_F2 = LEAN ? 2 * 512 : 0; // float2 units: two table slots of 256 float4 per wave
+};
 
-// LDS (float2 units).  !LEAN: the source loop's exchange slices and the epilogue's fd[wave][ear][512] + two slices
-// + output alias each other.  LEAN: fd IS the running sum of every wave (its spectra accumulators live in LDS, not
-// in 32 VGPRs), so it sits in front and the exchange slices behind it; the epilogue reuses the slices.
-template <int SQ>
+// LDS (float2 units).  The source loop's exchange slices (+ table slots) and the epilogue's fd[wave][ear][512] + two
+// slices + output alias each other.
+template <int SQ, int UW>
 struct UniLds {
 	static constexpr int F = 2 * SQ * 64;
 	static constexpr int FD_F2 = UW * 2 * 512; // fd[wave][ear][512]
 	static constexpr int EPI_F2 = FD_F2 + 2 * LDS_F2_HALF + F; // + two exchange slices + the [F][2] output
-	static constexpr int LOOP_F2 = (LEAN ? FD_F2 : 0) + UW * UNI_SLICES * LDS_F2_HALF; // source loop: exchange slices per wave
+	static constexpr int LOOP_F2 = UW * (UniCfg<UW>::SLICES * LDS_F2_HALF + UniCfg<UW>::TSLOT_F2);
 	static constexpr int TOTAL_F2 = EPI_F2 > LOOP_F2 ? EPI_F2 : LOOP_F2;
 };
 
@@ -73,22 +76,24 @@ struct UniLds {
 // bus b with weight w_b = (dry_bus == b) + (send_bus == b ? send : 0) per ear.  Bus 0 keeps the register sums (weighted),
 // bus 1's sums live in LDS (64 KB the plain form does not use) and are only touched by sources that reach it; the
 // epilogue runs once per bus.  Partial rows of bus b: [b * bus_rows + p_offset + workgroup].
-template <int SQ, bool SRC_PCM, bool BUS2 = false>
-__global__ __launch_bounds__(UW * 64, LEAN ? 3 : GAS_HRTF_WAVES_PER_SIMD) void k_hrtf_uni(gas_group_args g, const uint32_t *__restrict__ peak_bits, uint32_t peak_all, gas_dev_state st, gas_hrtf_table tab, const float2 *__restrict__ tw, float *__restrict__ partials, uint32_t p_offset, gas_cursor *__restrict__ cursors, const float *__restrict__ fade_env, const gas_params *__restrict__ fresh, gas_deferred_reduce job, const gas_bus_route *__restrict__ routes = nullptr, uint32_t bus_rows = 0) {
-	static_assert(!BUS2 || (!SRC_PCM && !LEAN), "the two-bus form exists for float rows at 2 waves per SIMD");
+template <int SQ, bool SRC_PCM, bool BUS2, int UW>
+__global__ __launch_bounds__(UW * 64, UW > 8 ? 3 : GAS_HRTF_WAVES_PER_SIMD) void k_hrtf_uni(gas_group_args g, const uint32_t *__restrict__ peak_bits, uint32_t peak_all, gas_dev_state st, gas_hrtf_table tab, const float2 *__restrict__ tw, float *__restrict__ partials, uint32_t p_offset, gas_cursor *__restrict__ cursors, const float *__restrict__ fade_env, const gas_params *__restrict__ fresh, gas_deferred_reduce job, const gas_bus_route *__restrict__ routes, uint32_t bus_rows) {
+	constexpr bool LEAN = UniCfg<UW>::LEAN;
+	constexpr int UNI_SLICES = UniCfg<UW>::SLICES;
+	static_assert(!LEAN || (!SRC_PCM && !BUS2), "the twelve-wave form exists for float rows on one bus");
 	constexpr int FQ = 2 * SQ; // F / 64
 	constexpr int HQ = 8 - SQ; // hist_len / 64
 	constexpr int NQ = 8 + SQ; // (hist_len + F) / 64
 	constexpr uint32_t F = FQ * 64;
 	constexpr uint32_t HL = HQ * 64;
-	constexpr int FD_F2 = UniLds<SQ>::FD_F2;
-	__shared__ float2 lds_all[UniLds<SQ>::TOTAL_F2];
+	constexpr int FD_F2 = UniLds<SQ, UW>::FD_F2;
+	__shared__ float2 lds_all[UniLds<SQ, UW>::TOTAL_F2];
 	__shared__ float2 tw_lds[1024];
 	__shared__ float2 bus1_all[BUS2 ? UW * 2 * 512 : 1]; // bus 1: [wave][ear][512], the layout of the epilogue's fd
 	const int lane = threadIdx.x & 63;
 	const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-	float2 *lds = lds_all + (LEAN ? FD_F2 : 0) + wave * (UNI_SLICES * LDS_F2_HALF);
-	float2 *acc = lds_all + wave * 2 * 512; // LEAN: this wave's fd rows (left ear, then right)
+	float2 *lds = lds_all + wave * (UNI_SLICES * LDS_F2_HALF);
+	float4 *tslot = reinterpret_cast<float4 *>(lds_all + UW * UNI_SLICES * LDS_F2_HALF) + wave * 512; // LEAN: this wave's two table slots
 	float *my_partial = partials + ((size_t)p_offset + blockIdx.x) * (size_t)(F * 2);
 	GAS_UNI_STAMP(0);
 #ifdef GAS_STAMPS
@@ -119,8 +124,6 @@ __global__ __launch_bounds__(UW * 64, LEAN ? 3 : GAS_HRTF_WAVES_PER_SIMD) void k
 	}
 	gas_audio_frame raw[FQ]; // frames lane + 64 q of the source in flight
 	float rawh[HQ]; // its history samples (lane-major rows: one 16-byte access per lane at F = 512)
-	gas_audio_frame rawB[UD > 1 ? FQ : 1]; // UD == 2: a second landing set, the source after that one
-	float rawhB[UD > 1 ? HQ : 1];
 	if (first < last) { // wave-uniform
 		SrcMeta m0{};
 		m0.slot = (uint32_t)__builtin_amdgcn_readlane((int)lm.slot, 0);
@@ -128,15 +131,6 @@ __global__ __launch_bounds__(UW * 64, LEAN ? 3 : GAS_HRTF_WAVES_PER_SIMD) void k
 		load_history<HQ>(st.hrtf_hist + (size_t)m0.slot * HL, lane, rawh);
 		if constexpr (!SRC_PCM) {
 			load_window<false, FQ>(g, m0, lane, fade_env, raw);
-		}
-	}
-	if constexpr (UD > 1 && !SRC_PCM) {
-		if (first + 1 < last) {
-			SrcMeta m1{};
-			m1.slot = (uint32_t)__builtin_amdgcn_readlane((int)lm.slot, 1);
-			m1.row = (uint32_t)__builtin_amdgcn_readlane((int)lm.row, 1);
-			load_history<HQ>(st.hrtf_hist + (size_t)m1.slot * HL, lane, rawhB);
-			load_window<false, FQ>(g, m1, lane, fade_env, rawB);
 		}
 	}
 	uint32_t my_flag = 0; // this lane's source needs its exact peak
@@ -174,6 +168,20 @@ __global__ __launch_bounds__(UW * 64, LEAN ? 3 : GAS_HRTF_WAVES_PER_SIMD) void k
 			load_window<true, FQ>(g, bcast_meta<true>(lm, 0, F), lane, fade_env, raw); // needs the cursor
 		}
 	}
+	// LEAN: the stored half of source i's HRIR row, global -> LDS slot (i & 1), 4 x 1 KiB, no VGPR landing set
+	auto table_dma = [&](uint32_t dir, uint32_t i) {
+		const float4 *row = tab.spec + (size_t)dir * 256 + lane;
+		float4 *dst = tslot + (i & 1u) * 256;
+#pragma unroll
+		for (int p = 0; p < 4; p++) {
+			__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(row + p * 64), (__attribute__((address_space(3))) void *)(dst + p * 64), 16, 0, 0);
+		}
+	};
+	if constexpr (LEAN) {
+		if (first < last) {
+			table_dma((uint32_t)__builtin_amdgcn_readlane((int)lm.dir, 0), 0u);
+		}
+	}
 #pragma unroll
 	for (int r = 0; r < TW_PER; r++) {
 		if (threadIdx.x + r * UW * 64 < 512) {
@@ -182,85 +190,67 @@ __global__ __launch_bounds__(UW * 64, LEAN ? 3 : GAS_HRTF_WAVES_PER_SIMD) void k
 	}
 	__syncthreads();
 	float2 t1[8], t2[8];
+#pragma unroll
+	for (int k = 0; k < 8; k++) {
+		t1[k] = tw_lds[k * 64 + lane];
+		t2[k] = tw_lds[(8 + k) * 64 + lane];
+	}
+	// gain ramp weights of this lane's frames, t = f/F and 1 - t (exact for F = 128 .. 512): the same for every source
+	// (LEAN rebuilds them per source, as k_hrtf_multi does: it has no registers to park them in)
+	float tq[LEAN ? 1 : FQ], omtq[LEAN ? 1 : FQ];
 	if constexpr (!LEAN) {
 #pragma unroll
-		for (int k = 0; k < 8; k++) {
-			t1[k] = tw_lds[k * 64 + lane];
-			t2[k] = tw_lds[(8 + k) * 64 + lane];
+		for (int q = 0; q < FQ; q++) {
+			tq[q] = (float)(lane + 64 * q) * (1.0f / (float)F);
+			omtq[q] = 1 - tq[q];
 		}
 	}
-	auto fwd = [&](float2(&v)[8], float2 *slice) {
-		if constexpr (LEAN) {
-			fft512_twlds<false>(v, tw_lds, slice, lane);
-		} else {
-			fft512<false>(v, t1, t2, slice, lane);
-		}
-	};
-	auto inv = [&](float2(&v)[8], float2 *slice) {
-		if constexpr (LEAN) {
-			fft512_twlds<true>(v, tw_lds, slice, lane);
-		} else {
-			fft512<true>(v, t1, t2, slice, lane);
-		}
-	};
-	// gain ramp weights of this lane's frames, t = f/F and 1 - t (exact for F = 128 .. 512): the same for every source
-	float tq[FQ], omtq[FQ];
-#pragma unroll
-	for (int q = 0; q < FQ; q++) {
-		tq[q] = (float)(lane + 64 * q) * (1.0f / (float)F);
-		omtq[q] = 1 - tq[q];
-	}
+	const float lane_f = (float)lane;
 	GAS_UNI_STAMP(1);
 
-	// ---- source loop: one forward FFT per source; its spectral products are taken one transform later (the HRIR
-	// row can only be requested once the direction is known, and travels while the next source is transformed) ----
+	// ---- source loop: one forward FFT per source.  8 waves: its spectral products are taken one transform later (the
+	// HRIR row can only be requested once the direction is known, and travels to VGPRs while the next source is
+	// transformed).  12 waves: the row has been travelling to LDS since the previous trip -----------------------------
 	float2 aYL[8], aYR[8]; // sum_s Z_s H_L[d_s], sum_s Z_s H_R[d_s] of this wave's sources
-	float2 zp[8]; // spectrum of the previous source, its table row (hs) in flight
-	float4 hs[8];
+	float2 zp[LEAN ? 1 : 8]; // spectrum of the previous source, its table row (hs) in flight
+	float4 hs[LEAN ? 1 : 8];
 #pragma unroll
 	for (int j = 0; j < 8; j++) {
 		aYL[j] = make_float2(0.0f, 0.0f);
 		aYR[j] = make_float2(0.0f, 0.0f);
-		zp[j] = make_float2(0.0f, 0.0f);
+		if constexpr (!LEAN) {
+			zp[j] = make_float2(0.0f, 0.0f);
+		}
 	}
 	bool have_prev = false; // wave-uniform
 	uint32_t prev_flag = 0, prev_row = 0;
 	float pw0l = 1.0f, pw0r = 1.0f, pw1l = 0.0f, pw1r = 0.0f; // BUS2: the previous source's bus weights (wave-uniform)
-	if constexpr (LEAN) {
+
+	// LEAN: the products of a source right after its transform, its row read from the wave's LDS slot (slot_read_spectra)
+	auto products_now = [&](const float2(&z)[8], uint32_t flag, uint32_t row, const float4 *slot) {
+		float4 h[8];
+		slot_read_spectra(slot, lane, h);
 #pragma unroll
 		for (int j = 0; j < 8; j++) {
-			acc[j * 64 + lane] = make_float2(0.0f, 0.0f);
-			acc[512 + j * 64 + lane] = make_float2(0.0f, 0.0f);
+			cmac_fixed(aYL[j], z[j], h[j].x, h[j].y);
+			cmac_fixed(aYR[j], z[j], h[j].z, h[j].w);
 		}
-	}
-
-	// LEAN: the products of a source right after its transform (its row was requested before the transform)
-	auto products_now = [&](const float2(&z)[8], uint32_t flag, uint32_t row) {
-		finish_spectra(lane, hs);
 		if (!flag) { // wave-uniform
-#pragma unroll
-			for (int j = 0; j < 8; j++) {
-				float2 al = acc[j * 64 + lane], ar = acc[512 + j * 64 + lane];
-				cmac_fixed(al, z[j], hs[j].x, hs[j].y);
-				cmac_fixed(ar, z[j], hs[j].z, hs[j].w);
-				acc[j * 64 + lane] = al;
-				acc[512 + j * 64 + lane] = ar;
-			}
 			return;
 		}
-		// exact peak: one ear after the other through the wave's single exchange slice
-		float2 y[8];
+		// exact peak: one ear after the other through the wave's single exchange slice.  The inverse transforms take
+		// their twiddles from the LDS copy at the point of use and the register copy is reloaded afterwards: 30 VGPRs
+		// that are not live across this (rare) path.  Same twiddle values, same operations: the bits of fft512.
 		float pk[2];
 #pragma unroll
 		for (int ear = 0; ear < 2; ear++) {
+			float2 y[8];
 #pragma unroll
 			for (int j = 0; j < 8; j++) {
-				y[j] = cmul_fixed(z[j], ear == 0 ? hs[j].x : hs[j].z, ear == 0 ? hs[j].y : hs[j].w);
-				float2 a = acc[ear * 512 + j * 64 + lane];
-				cmac_fixed(a, z[j], ear == 0 ? hs[j].x : hs[j].z, ear == 0 ? hs[j].y : hs[j].w);
-				acc[ear * 512 + j * 64 + lane] = a;
+				y[j] = cmul_fixed(z[j], ear == 0 ? h[j].x : h[j].z, ear == 0 ? h[j].y : h[j].w);
 			}
-			inv(y, lds);
+			asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the compiler's ds_reads below would wait for the DMA anyway
+			fft512_twlds<true>(y, tw_lds, lds, lane);
 			float p = 0.0f;
 #pragma unroll
 			for (int t = 0; t < SQ; t++) {
@@ -272,93 +262,115 @@ __global__ __launch_bounds__(UW * 64, LEAN ? 3 : GAS_HRTF_WAVES_PER_SIMD) void k
 			g.peaks[(size_t)row * 2] = pk[0];
 			g.peaks[(size_t)row * 2 + 1] = pk[1];
 		}
+#pragma unroll
+		for (int k = 0; k < 8; k++) {
+			t1[k] = tw_lds[k * 64 + lane];
+			t2[k] = tw_lds[(8 + k) * 64 + lane];
+		}
 	};
 
-	// products of the previous source (zp x hs), its exact peak if asked for, then the request for `next_dir`'s row
+	// 8 waves: products of the previous source (zp x hs), its exact peak if asked for, then the request for `next_dir`'s row
 	auto products = [&](bool more, uint32_t next_dir) {
-		float2 yl[8], yr[8];
-		if (have_prev && BUS2) {
-			finish_spectra(lane, hs);
-			float2 *b1 = bus1_all + wave * 2 * 512;
-			const bool to1 = pw1l != 0.0f || pw1r != 0.0f; // wave-uniform
-#pragma unroll
-			for (int j = 0; j < 8; j++) {
-				yl[j] = cmul_fixed(zp[j], hs[j].x, hs[j].y);
-				yr[j] = cmul_fixed(zp[j], hs[j].z, hs[j].w);
-				aYL[j] = make_float2(__builtin_fmaf(pw0l, yl[j].x, aYL[j].x), __builtin_fmaf(pw0l, yl[j].y, aYL[j].y));
-				aYR[j] = make_float2(__builtin_fmaf(pw0r, yr[j].x, aYR[j].x), __builtin_fmaf(pw0r, yr[j].y, aYR[j].y));
-			}
-			if (to1) {
-#pragma unroll
-				for (int j = 0; j < 8; j++) {
-					float2 a = b1[j * 64 + lane], b = b1[512 + j * 64 + lane];
-					a = make_float2(__builtin_fmaf(pw1l, yl[j].x, a.x), __builtin_fmaf(pw1l, yl[j].y, a.y));
-					b = make_float2(__builtin_fmaf(pw1r, yr[j].x, b.x), __builtin_fmaf(pw1r, yr[j].y, b.y));
-					b1[j * 64 + lane] = a;
-					b1[512 + j * 64 + lane] = b;
-				}
-			}
-		} else if (have_prev) {
-			finish_spectra(lane, hs);
-#pragma unroll
-			for (int j = 0; j < 8; j++) {
-				cmac_fixed(aYL[j], zp[j], hs[j].x, hs[j].y);
-				cmac_fixed(aYR[j], zp[j], hs[j].z, hs[j].w);
-			}
-			if (prev_flag) { // wave-uniform: this source's own output spectra (before the row's registers are requested again)
+		if constexpr (!LEAN) {
+			float2 yl[8], yr[8];
+			if (have_prev && BUS2) {
+				finish_spectra(lane, hs);
+				float2 *b1 = bus1_all + wave * 2 * 512;
+				const bool to1 = pw1l != 0.0f || pw1r != 0.0f; // wave-uniform
 #pragma unroll
 				for (int j = 0; j < 8; j++) {
 					yl[j] = cmul_fixed(zp[j], hs[j].x, hs[j].y);
 					yr[j] = cmul_fixed(zp[j], hs[j].z, hs[j].w);
+					aYL[j] = make_float2(__builtin_fmaf(pw0l, yl[j].x, aYL[j].x), __builtin_fmaf(pw0l, yl[j].y, aYL[j].y));
+					aYR[j] = make_float2(__builtin_fmaf(pw0r, yr[j].x, aYR[j].x), __builtin_fmaf(pw0r, yr[j].y, aYR[j].y));
+				}
+				if (to1) {
+#pragma unroll
+					for (int j = 0; j < 8; j++) {
+						float2 a = b1[j * 64 + lane], b = b1[512 + j * 64 + lane];
+						a = make_float2(__builtin_fmaf(pw1l, yl[j].x, a.x), __builtin_fmaf(pw1l, yl[j].y, a.y));
+						b = make_float2(__builtin_fmaf(pw1r, yr[j].x, b.x), __builtin_fmaf(pw1r, yr[j].y, b.y));
+						b1[j * 64 + lane] = a;
+						b1[512 + j * 64 + lane] = b;
+					}
+				}
+			} else if (have_prev) {
+				finish_spectra(lane, hs);
+#pragma unroll
+				for (int j = 0; j < 8; j++) {
+					cmac_fixed(aYL[j], zp[j], hs[j].x, hs[j].y);
+					cmac_fixed(aYR[j], zp[j], hs[j].z, hs[j].w);
+				}
+				if (prev_flag) { // wave-uniform: this source's own output spectra (before the row's registers are requested again)
+#pragma unroll
+					for (int j = 0; j < 8; j++) {
+						yl[j] = cmul_fixed(zp[j], hs[j].x, hs[j].y);
+						yr[j] = cmul_fixed(zp[j], hs[j].z, hs[j].w);
+					}
 				}
 			}
-		}
-		if (more) {
-			issue_spectra(tab.spec, next_dir, lane, hs);
-		}
-		if (have_prev && prev_flag) { // wave-uniform: this source's own output, for max |L|, max |R| (:436-443)
-			if constexpr (!LEAN && SRC_PCM) { // the stream-sampling form has no registers for the interleaved pair (same operations, same bits)
-				fft512<true>(yl, t1, t2, lds, lane);
-				fft512<true>(yr, t1, t2, lds + LDS_F2_HALF, lane);
-			} else if constexpr (!LEAN) {
-				fft512_pair<true>(yl, yr, t1, t2, lds, lds + LDS_F2_HALF, lane);
+			if (more) {
+				issue_spectra(tab.spec, next_dir, lane, hs);
 			}
-			float pkl = 0.0f, pkr = 0.0f;
+			if (have_prev && prev_flag) { // wave-uniform: this source's own output, for max |L|, max |R| (:436-443)
+				if constexpr (SRC_PCM) { // the stream-sampling form has no registers for the interleaved pair (same operations, same bits)
+					fft512<true>(yl, t1, t2, lds, lane);
+					fft512<true>(yr, t1, t2, lds + LDS_F2_HALF, lane);
+				} else {
+					fft512_pair<true>(yl, yr, t1, t2, lds, lds + LDS_F2_HALF, lane);
+				}
+				float pkl = 0.0f, pkr = 0.0f;
 #pragma unroll
-			for (int t = 0; t < SQ; t++) { // valid outputs are window positions [512 - S, 512): registers j >= HQ
-				pkl = fmaxf(pkl, fmaxf(fabsf(yl[HQ + t].x), fabsf(yl[HQ + t].y)));
-				pkr = fmaxf(pkr, fmaxf(fabsf(yr[HQ + t].x), fabsf(yr[HQ + t].y)));
-			}
-			pkl = wave_max(pkl);
-			pkr = wave_max(pkr);
-			if (lane == 0) {
-				g.peaks[(size_t)prev_row * 2] = pkl;
-				g.peaks[(size_t)prev_row * 2 + 1] = pkr;
+				for (int t = 0; t < SQ; t++) { // valid outputs are window positions [512 - S, 512): registers j >= HQ
+					pkl = fmaxf(pkl, fmaxf(fabsf(yl[HQ + t].x), fabsf(yl[HQ + t].y)));
+					pkr = fmaxf(pkr, fmaxf(fabsf(yr[HQ + t].x), fabsf(yr[HQ + t].y)));
+				}
+				pkl = wave_max(pkl);
+				pkr = wave_max(pkr);
+				if (lane == 0) {
+					g.peaks[(size_t)prev_row * 2] = pkl;
+					g.peaks[(size_t)prev_row * 2 + 1] = pkr;
+				}
 			}
 		}
 	};
 
-	constexpr uint32_t AHEAD = (UD > 1 && !SRC_PCM) ? 2 : 1; // the landing set freed by source e is refilled with source e + AHEAD
 	for (uint32_t e = first; e < last; e++) {
-		const bool use_b = AHEAD == 2 && ((e - first) & 1u) != 0; // wave-uniform: which landing set holds source e
-		const bool has_next = e + AHEAD < last;
+		const bool has_next = e + 1 < last;
 		const SrcMeta m = bcast_meta<SRC_PCM>(lm, e - first, F);
-		const SrcMeta mn = bcast_meta<SRC_PCM>(lm, has_next ? e + AHEAD - first : e - first, F);
+		const SrcMeta mn = bcast_meta<SRC_PCM>(lm, has_next ? e + 1 - first : e - first, F);
 		const uint32_t flag = (uint32_t)__builtin_amdgcn_readlane((int)my_flag, (int)(e - first));
+		if constexpr (LEAN) {
+			// Everything this trip consumes has landed: the frames and history requested a trip ago, and -- older than
+			// those in the wave's vector-memory queue, which retires in order -- this source's table row.  The next
+			// source's row starts for the other slot now and has the whole trip to arrive.
+			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+			if (has_next) {
+				table_dma(mn.dir, e + 1 - first);
+			}
+		}
 
 		// x_full[lane + 64 q]: q < HQ from the history, the rest from this callback's frames
 		float xq[NQ];
 #pragma unroll
 		for (int q = 0; q < HQ; q++) {
-			xq[q] = use_b ? rawhB[UD > 1 ? q : 0] : rawh[q];
+			xq[q] = rawh[q];
 		}
+		if constexpr (LEAN) {
+			float lf = lane_f;
+			asm volatile("" : "+v"(lf)); // keeps the ramp weights out of registers across the loop (k_hrtf_multi's form, same bits)
 #pragma unroll
-		for (int q = 0; q < FQ; q++) {
-			const int f = lane + 64 * q;
-			const gas_audio_frame rq = use_b ? rawB[UD > 1 ? q : 0] : raw[q];
-			const float mono = (rq.left + rq.right) * 0.5f;
-			xq[HQ + q] = mono * (m.g1 * tq[q] + omtq[q] * m.g0);
-			(void)f;
+			for (int q = 0; q < FQ; q++) {
+				const float mono = (raw[q].left + raw[q].right) * 0.5f;
+				const float t = (lf + (float)(64 * q)) * (1.0f / (float)F);
+				xq[HQ + q] = mono * (m.g1 * t + (1 - t) * m.g0);
+			}
+		} else {
+#pragma unroll
+			for (int q = 0; q < FQ; q++) {
+				const float mono = (raw[q].left + raw[q].right) * 0.5f;
+				xq[HQ + q] = mono * (m.g1 * tq[q] + omtq[q] * m.g0);
+			}
 		}
 #ifdef GAS_STAMPS
 		if (e == first) {
@@ -374,50 +386,9 @@ __global__ __launch_bounds__(UW * 64, LEAN ? 3 : GAS_HRTF_WAVES_PER_SIMD) void k
 				}
 			}
 		}
-		if constexpr (!SRC_PCM && GAS_UNI_UNIFORM_NEXT) {
-			// EXPERIMENT (off): the next source's history and frames requested on EVERY trip -- the last one re-reads the
-			// (L2-resident) twiddle table into registers nobody uses -- so that the loop body has no branch around its
-			// loads.  With the branch the compiler, which counts vmcnt per path and takes the smallest count at a join,
-			// waits for the HRIR row with vmcnt(4..1), i.e. also for most of the frames it has just requested; without it
-			// the waits are exact (vmcnt(13..10)).  Measured: no gain (15.6 -> 16.1 us at 8192 sources, 90.3 -> 90.0 at
-			// 65536) -- the frames' flight is not what a trip waits for (profiles/r02_notes.md); GAS_UNI_DEPTH=2 (a second
-			// landing set, two sources in flight per wave) likewise: 16.5 / 92 us.
-			const gas_audio_frame *nsrc = has_next ? g.src + (size_t)mn.row * F : reinterpret_cast<const gas_audio_frame *>(tw);
-			const float *nhist = has_next ? st.hrtf_hist + (size_t)mn.slot * HL : reinterpret_cast<const float *>(tw);
-			if constexpr (AHEAD == 2) {
-				if (use_b) {
-					load_history<HQ>(nhist, lane, rawhB);
-#pragma unroll
-					for (int q = 0; q < FQ; q++) {
-						rawB[UD > 1 ? q : 0] = nt_load_frame(nsrc + lane + 64 * q);
-					}
-				} else {
-					load_history<HQ>(nhist, lane, rawh);
-#pragma unroll
-					for (int q = 0; q < FQ; q++) {
-						raw[q] = nt_load_frame(nsrc + lane + 64 * q);
-					}
-				}
-			} else {
-				load_history<HQ>(nhist, lane, rawh);
-#pragma unroll
-				for (int q = 0; q < FQ; q++) {
-					raw[q] = nt_load_frame(nsrc + lane + 64 * q);
-				}
-			}
-		} else if (has_next) {
-			if constexpr (AHEAD == 2) {
-				if (use_b) {
-					load_history<HQ>(st.hrtf_hist + (size_t)mn.slot * HL, lane, rawhB);
-					load_window<SRC_PCM, FQ>(g, mn, lane, fade_env, rawB);
-				} else {
-					load_history<HQ>(st.hrtf_hist + (size_t)mn.slot * HL, lane, rawh);
-					load_window<SRC_PCM, FQ>(g, mn, lane, fade_env, raw);
-				}
-			} else {
-				load_history<HQ>(st.hrtf_hist + (size_t)mn.slot * HL, lane, rawh);
-				load_window<SRC_PCM, FQ>(g, mn, lane, fade_env, raw);
-			}
+		if (has_next) {
+			load_history<HQ>(st.hrtf_hist + (size_t)mn.slot * HL, lane, rawh);
+			load_window<SRC_PCM, FQ>(g, mn, lane, fade_env, raw);
 		}
 		// z = a + i b : a = x_full[0..512), b = x_full[S..S+512) -- one complex FFT serves both sub-blocks
 		float2 zs[8];
@@ -426,13 +397,12 @@ __global__ __launch_bounds__(UW * 64, LEAN ? 3 : GAS_HRTF_WAVES_PER_SIMD) void k
 			zs[j] = make_float2(xq[j], xq[j + SQ]);
 		}
 		if constexpr (LEAN) {
-			issue_spectra(tab.spec, m.dir, lane, hs); // lands under the transform
-			fwd(zs, lds);
-			products_now(zs, flag, m.row);
+			fft512_ar<false>(zs, t1, t2, lds, lane);
+			products_now(zs, flag, m.row, tslot + ((e - first) & 1u) * 256);
 		} else {
+			fft512<false>(zs, t1, t2, lds, lane);
 			// the products of a transform are taken one transform later (measured: taking them in front of the next
 			// transform instead, which saves the 16-register copy, costs 0.5 us per launch -- the row needs the time)
-			fwd(zs, lds);
 			products(true, m.dir);
 #pragma unroll
 			for (int j = 0; j < 8; j++) {
@@ -482,29 +452,25 @@ __global__ __launch_bounds__(UW * 64, LEAN ? 3 : GAS_HRTF_WAVES_PER_SIMD) void k
 			job_issue(job, job_col, lane, jr);
 		}
 	}
-	if constexpr (!LEAN) {
-		products(false, 0); // the last source's products (and peak)
-	}
+	products(false, 0); // 8 waves: the last source's products (and peak)
 
 	// ---- epilogue: spectra of all waves -> fd[wave][ear][j][lane]; wave 0 transforms the left ear's sum and wave 1
 	// the right ear's; the workgroup stores one interleaved time-domain partial mix ----------------------------------
 	float2 *fd = lds_all;
 	float *outp = reinterpret_cast<float *>(lds_all + FD_F2 + 2 * LDS_F2_HALF);
-	if constexpr (!LEAN) {
-		__syncthreads(); // every wave is done with its exchange slices (fd aliases them)
+	__syncthreads(); // every wave is done with its exchange slices and table slots (fd aliases them)
 #pragma unroll
-		for (int j = 0; j < 8; j++) {
-			fd[(wave * 2 + 0) * 512 + j * 64 + lane] = aYL[j];
-			fd[(wave * 2 + 1) * 512 + j * 64 + lane] = aYR[j];
-		}
+	for (int j = 0; j < 8; j++) {
+		fd[(wave * 2 + 0) * 512 + j * 64 + lane] = aYL[j];
+		fd[(wave * 2 + 1) * 512 + j * 64 + lane] = aYR[j];
 	}
-	__syncthreads(); // fd is complete (LEAN: it has been every wave's running sum all along)
+	__syncthreads(); // fd is complete
 	GAS_UNI_STAMP(4);
 	if (job_mine) {
 		job_finish(job, job_col, lane, jr);
 	}
 	if (wave < 2) {
-		// wave `ear` adds the WAVES spectra of its ear in wave order: ((w0 + w1) + w2) + ...
+		// wave `ear` adds the UW spectra of its ear in wave order: ((w0 + w1) + w2) + ...
 		float2 y[8];
 #pragma unroll
 		for (int j = 0; j < 8; j++) {
@@ -517,7 +483,7 @@ __global__ __launch_bounds__(UW * 64, LEAN ? 3 : GAS_HRTF_WAVES_PER_SIMD) void k
 				y[j] = cadd(y[j], fd[(w * 2 + wave) * 512 + j * 64 + lane]);
 			}
 		}
-		inv(y, lds_all + FD_F2 + wave * LDS_F2_HALF);
+		fft512<true>(y, t1, t2, lds_all + FD_F2 + wave * LDS_F2_HALF, lane);
 #pragma unroll
 		for (int t = 0; t < SQ; t++) {
 			const int fa = lane + 64 * t, fb = lane + 64 * (SQ + t);
@@ -544,7 +510,7 @@ __global__ __launch_bounds__(UW * 64, LEAN ? 3 : GAS_HRTF_WAVES_PER_SIMD) void k
 					y[j] = cadd(y[j], bus1_all[(w * 2 + wave) * 512 + j * 64 + lane]);
 				}
 			}
-			inv(y, lds_all + FD_F2 + wave * LDS_F2_HALF);
+			fft512<true>(y, t1, t2, lds_all + FD_F2 + wave * LDS_F2_HALF, lane);
 #pragma unroll
 			for (int t = 0; t < SQ; t++) {
 				const int fa = lane + 64 * t, fb = lane + 64 * (SQ + t);
@@ -569,58 +535,65 @@ __global__ __launch_bounds__(UW * 64, LEAN ? 3 : GAS_HRTF_WAVES_PER_SIMD) void k
 } // namespace
 
 // One workgroup per CU (one residency round), at least one source per wave, at most 64 (one metadata lane each).
+// The grid is sized for the eight-wave form; the twelve-wave form runs on the same grid (same partial rows) whenever
+// every one of its waves still gets a source.
+constexpr uint32_t UNI_W = 8, UNI_W12 = 12;
+
 uint32_t gas_hrtf_uni_waves() {
-	return UW;
+	return UNI_W;
 }
 
 uint32_t gas_hrtf_uni_partials(uint32_t n) {
-	const uint32_t want = (n + UW - 1) / UW, need = (n + UW * 64 - 1) / (UW * 64);
-	const uint32_t round = UW < 8 ? 256u * (8 / UW) : 256u; // workgroups resident at once
-	const uint32_t w = want < round ? want : round;
+	const uint32_t want = (n + UNI_W - 1) / UNI_W, need = (n + UNI_W * 64 - 1) / (UNI_W * 64);
+	const uint32_t w = want < 256u ? want : 256u; // workgroups resident at once
 	return w > need ? w : need;
+}
+
+// Which callbacks run three waves per SIMD: those of at least this many sources (0 = none).  Default: the build's
+// GAS_UNI12_DEFAULT_MIN, overridden by the environment variable GAS_UNI12_MIN (read once) or gas_tune_uni12_min().
+static uint32_t g_uni12_min = [] {
+	const char *e = getenv("GAS_UNI12_MIN");
+	return e ? (uint32_t)strtoul(e, nullptr, 10) : (uint32_t)GAS_UNI12_DEFAULT_MIN;
+}();
+
+static uint32_t uni12_min_sources() {
+	return g_uni12_min;
+}
+
+extern "C" uint32_t gas_tune_uni12_min(uint32_t min_sources) {
+	const uint32_t was = g_uni12_min;
+	g_uni12_min = min_sources;
+	return was;
+}
+
+bool gas_hrtf_uni_twelve(uint32_t n, bool streams, bool buses) {
+	const uint32_t wgs = gas_hrtf_uni_partials(n), mn = uni12_min_sources();
+	return !streams && !buses && mn != 0 && n >= mn && n >= wgs * UNI_W12 && n <= wgs * UNI_W12 * 64;
 }
 
 hipError_t gas_launch_hrtf_uni(hipStream_t stream, const gas_group_args &g, const uint32_t *peak_bits, bool peak_all, const gas_dev_state &st, const gas_hrtf_table &tab, const float2 *twiddles, uint32_t frames, uint32_t hist_len, float *partials, uint32_t p_offset, gas_cursor *cursors, const float *fade_env, const gas_params *fresh, const gas_deferred_reduce &job, const gas_bus_route *routes, uint32_t bus_rows) {
 	if (g.n == 0) {
 		return hipSuccess;
 	}
-	if (routes) { // the two-bus form (gas_process_block_buses over [HRTF] sources)
-		if (LEAN || cursors || g.order || frames % 128 != 0 || frames > 512 || hist_len != 512 - frames / 2) {
-			return hipErrorInvalidValue;
-		}
-		const uint32_t bwgs = gas_hrtf_uni_partials(g.n);
-		const uint32_t ball = peak_all ? 1u : 0u;
-		if constexpr (!LEAN) {
-			switch (frames / 128) {
-				case 1:
-					hipLaunchKernelGGL((k_hrtf_uni<1, false, true>), dim3(bwgs), dim3(UW * 64), 0, stream, g, peak_bits, ball, st, tab, twiddles, partials, p_offset, cursors, fade_env, fresh, job, routes, bus_rows);
-					break;
-				case 2:
-					hipLaunchKernelGGL((k_hrtf_uni<2, false, true>), dim3(bwgs), dim3(UW * 64), 0, stream, g, peak_bits, ball, st, tab, twiddles, partials, p_offset, cursors, fade_env, fresh, job, routes, bus_rows);
-					break;
-				case 3:
-					hipLaunchKernelGGL((k_hrtf_uni<3, false, true>), dim3(bwgs), dim3(UW * 64), 0, stream, g, peak_bits, ball, st, tab, twiddles, partials, p_offset, cursors, fade_env, fresh, job, routes, bus_rows);
-					break;
-				default:
-					hipLaunchKernelGGL((k_hrtf_uni<4, false, true>), dim3(bwgs), dim3(UW * 64), 0, stream, g, peak_bits, ball, st, tab, twiddles, partials, p_offset, cursors, fade_env, fresh, job, routes, bus_rows);
-					break;
-			}
-		}
-		return hipGetLastError();
-	}
-	if (frames % 128 != 0 || frames > 512 || hist_len != 512 - frames / 2) {
+	if (frames % 128 != 0 || frames > 512 || hist_len != 512 - frames / 2 || (routes && (cursors || g.order))) {
 		return hipErrorInvalidValue;
 	}
 	const uint32_t wgs = gas_hrtf_uni_partials(g.n);
-	dim3 grid(wgs), block(UW * 64);
 	const uint32_t all = peak_all ? 1u : 0u;
-#define GAS_UNI_CASE(SQv)                                                                                                                                                     \
-	case SQv:                                                                                                                                                                  \
-		if (cursors) {                                                                                                                                                         \
-			hipLaunchKernelGGL((k_hrtf_uni<SQv, true>), grid, block, 0, stream, g, peak_bits, all, st, tab, twiddles, partials, p_offset, cursors, fade_env, fresh, job, (const gas_bus_route *)nullptr, 0u);     \
-		} else {                                                                                                                                                               \
-			hipLaunchKernelGGL((k_hrtf_uni<SQv, false>), grid, block, 0, stream, g, peak_bits, all, st, tab, twiddles, partials, p_offset, cursors, fade_env, fresh, job, (const gas_bus_route *)nullptr, 0u);    \
-		}                                                                                                                                                                      \
+	const bool twelve = gas_hrtf_uni_twelve(g.n, cursors != nullptr, routes != nullptr);
+	const dim3 grid(wgs), block((twelve ? UNI_W12 : UNI_W) * 64);
+#define GAS_UNI_GO(SQv, PCM, BUS, W) hipLaunchKernelGGL((k_hrtf_uni<SQv, PCM, BUS, W>), grid, block, 0, stream, g, peak_bits, all, st, tab, twiddles, partials, p_offset, cursors, fade_env, fresh, job, routes, bus_rows)
+#define GAS_UNI_CASE(SQv)                      \
+	case SQv:                                  \
+		if (routes) {                          \
+			GAS_UNI_GO(SQv, false, true, 8);   \
+		} else if (cursors) {                  \
+			GAS_UNI_GO(SQv, true, false, 8);   \
+		} else if (twelve) {                   \
+			GAS_UNI_GO(SQv, false, false, 12); \
+		} else {                               \
+			GAS_UNI_GO(SQv, false, false, 8);  \
+		}                                      \
 		break;
 	switch (frames / 128) {
 		GAS_UNI_CASE(1)
@@ -631,6 +604,7 @@ hipError_t gas_launch_hrtf_uni(hipStream_t stream, const gas_group_args &g, cons
 			return hipErrorInvalidValue;
 	}
 #undef GAS_UNI_CASE
+#undef GAS_UNI_GO
 	return hipGetLastError();
 }
 

@@ -366,6 +366,12 @@ int gas_profile_read(gas_ctx *ctx, gas_profile *out, int reset);
  * calibration as the dominant kernel; *out_us = average span of one launch on the GPU timeline over `iters` launches.
  * workgroups x 256 threads, `unroll` (1, 2, 4 or 8) independent loads in flight per thread. */
 int gas_bandwidth_probe(gas_ctx *ctx, uint64_t read_bytes, uint64_t write_bytes, uint32_t workgroups, uint32_t unroll, uint32_t iters, double *out_us);
+/* Tuning (process-wide, not per context): plain-[HRTF] callbacks of at least `min_sources` float-row sources on one
+ * bus run k_hrtf_uni's twelve-wave form (three waves per SIMD, HRIR rows staged through LDS); 0 = never.  The two
+ * forms split the sources over waves differently, so their mixes agree to rounding (1e-5 relative RMS), not to
+ * the bit.  The build's default: DESIGN.md 3.1; environment variable GAS_UNI12_MIN overrides it at load time.
+ * Returns the previous value. */
+uint32_t gas_tune_uni12_min(uint32_t min_sources);
 /* Diagnostic: the processing order the last gas_process_block used for its plain [HRTF] sources (GAS_FLAG_XCD_ORDER
  * only): out[i] = list entry processed i-th; waits for the stream.  GAS_ERR_INVALID_ARGUMENT when that
  * callback ran in list order. */
