@@ -52,21 +52,90 @@ N_SRC_BUFFERS_BYTES = int(os.environ.get("GAS_BENCH_SRC_BYTES", 320 << 20))  # r
 CONDITION_STEPS = 64  # untimed callbacks in front of the --warmup ones: clocks and caches settle independently of --warmup
 
 
+def lib_sha16():
+    """First 16 hex digits of the sha256 of the library this run loads: PMC records carry it, so a record taken with
+    another build of the kernels is refused instead of silently going stale."""
+    import hashlib
+
+    from godot_audio_spatializer_amd import capi
+
+    try:
+        return hashlib.sha256(open(capi.library_path(), "rb").read()).hexdigest()[:16]
+    except OSError:
+        return None
+
+
 def pmc_traffic(kernel, workload, n_local, peaks, pipelined, experiment=""):
     """HBM bytes per launch from the committed rocprofv3 PMC passes of this same command (profiles/*_pmc.json,
     written by tools/profile_bench.sh; FETCH_SIZE x2 + WRITE_SIZE), or None.  The newest
-    matching record wins (files sort by round)."""
+    matching record wins (files sort by round); a record taken with a different build of the library (lib_sha16) only
+    matches when GAS_BENCH_ACCEPT_STALE_PMC is set, and is then labelled stale."""
     import glob
 
     best = None
+    sha = lib_sha16()
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json"))):
         try:
             rec = json.load(open(path))
         except (OSError, ValueError):
             continue
         if rec.get("kernel") == kernel and rec.get("workload") == workload and rec.get("sources_per_gpu") == n_local and rec.get("peaks") == peaks and bool(rec.get("pipelined_mix", False)) == pipelined and rec.get("experiment", "") == experiment:
-            best = (rec["traffic_bytes_per_launch"], os.path.basename(path))
+            fresh = rec.get("lib_sha16") is not None and rec.get("lib_sha16") == sha
+            if fresh or os.environ.get("GAS_BENCH_ACCEPT_STALE_PMC"):
+                best = (rec["traffic_bytes_per_launch"], os.path.basename(path) + ("" if fresh else " [STALE: taken with another build of the library]"), rec)
     return best
+
+
+# Vector-ALU floor of the HRTF kernels: wave-level VALU instructions one source costs (static census of the code object,
+# tools/isa_blocks.py -> profiles/r03_isa_*.txt; cross-checked with SQ_INSTS_VALU per launch, profiles/r03_notes.md) x
+# the issue rate one SIMD sustains for them with two waves resident (tools/micro/valurate.hip: one wave64 f32 VALU
+# instruction per ~4 shader cycles per SIMD at 2 waves/SIMD -- not the 2 cycles of the SIMD-32 data path) over the
+# chip's 1024 SIMDs at the 2.4 GHz peak clock.  A floor, like the HBM floor beside it: nothing overlaps perfectly.
+VALU_PER_SOURCE = {"k_hrtf_multi": 384, "k_hrtf_uni": 388}
+VALU_CYCLES_PER_INST = 4.0
+SIMDS = 1024
+CLOCK_HZ = 2.4e9
+
+
+def roofline_entry(prof, n_sources, desc=None, peaks=None, pipelined=False, experiment=""):
+    """The `roofline` object of one timed pass (contract: achieved = bytes the launch must move / its average span)."""
+    launches = max(prof["launches"], 1)
+    k_us = prof["kernel_ms"] / launches * 1e3
+    B = prof["bytes_per_launch"]
+    K = max(1, prof.get("callbacks_per_launch", 1))
+    achieved = B / (k_us * 1e-6) if k_us > 0 else 0.0
+    r = {
+        "kernel": prof["kernel"],
+        "kernel_us": k_us,
+        "launches_timed": prof["launches"],
+        "callbacks_per_launch": K,
+        "algorithmic_bytes_per_launch": B,
+        "achieved": achieved / 1e9,
+        "peak": HBM_PEAK / 1e9,
+        "unit": "GB/s",
+        "frac": achieved / HBM_PEAK,
+        "hbm_floor_us": B / HBM_PEAK * 1e6,
+        "traffic": None,
+        "traffic_source": None,
+    }
+    if K > 1:
+        Bf = prof.get("bytes_per_callback_formula", B)
+        r["per_callback_formula"] = {"bytes_per_launch": Bf, "frac": (Bf / (k_us * 1e-6) / HBM_PEAK) if k_us > 0 else 0.0, "what": "SURVEY.md 8d's per-callback bytes x callbacks per launch (round 2's figure): counts the history rows and the HRIR table once per callback although the batched kernel moves them once per launch -- kept for comparison, not a roofline"}
+    vps = VALU_PER_SOURCE.get(prof["kernel"])
+    if vps:
+        r["valu_floor_us"] = vps * VALU_CYCLES_PER_INST * n_sources * K / SIMDS / CLOCK_HZ * 1e6
+        r["valu_per_source"] = vps
+        r["bound"] = "valu" if r["valu_floor_us"] > r["hbm_floor_us"] else "hbm"
+        r["bound_evidence"] = "the higher of the two floors (VALU wave-instructions per source x 4 cycles / (1024 SIMDs x 2.4 GHz) vs bytes / 8 TB/s); SQ counters of the same launch in profiles/ (SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES, SQ_WAIT_ANY)"
+    else:
+        r["bound"] = "hbm" if n_sources >= 4096 else "latency"
+    if desc is not None:
+        t = pmc_traffic(prof["kernel"], desc, n_sources, peaks, pipelined, experiment)
+        if t:
+            r["traffic"] = float(t[0])
+            r["traffic_source"] = "profiles/" + t[1] + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command; FETCH x2 on gfx950)"
+            r["traffic_over_algorithmic"] = float(t[0]) / B if B else None
+    return r
 
 
 def _cpu_worker(args):
@@ -406,8 +475,6 @@ def main():
     achieved = 0.0
     peaks_desc = "every source" if args.exact_peaks else f"draining sources only ({n_draining} of {n_local} per GPU)"
     if rank == 0:
-        k_ms = prof["kernel_ms"] / max(prof["launches"], 1)
-        achieved = prof["bytes_per_launch"] / (k_ms * 1e-3) if k_ms > 0 else 0.0
         rccl_ranks = dist.get_world_size() if world > 1 else 1
         result = {
             "metric": "mixed AudioFrames/s",
@@ -443,24 +510,10 @@ def main():
                 "reduce_bucket": run.B,
                 "realtime_budget_ms": frames / 48000.0 * 1e3,
             },
-            "roofline": {
-                "bound": "hbm",
-                "achieved": achieved / 1e9,
-                "peak": HBM_PEAK / 1e9,
-                "unit": "GB/s",
-                "frac": achieved / HBM_PEAK,
-                "traffic": None,
-                "traffic_source": None,
-                "kernel": prof["kernel"],
-                "kernel_us": k_ms * 1e3,
-                "launches_timed": prof["launches"],
-                "algorithmic_bytes_per_launch": prof["bytes_per_launch"],
-            },
+            "roofline": roofline_entry(prof, n_local, desc, peaks_desc, not args.no_pipelined_mix, experiment),
         }
-        t = pmc_traffic(result["roofline"]["kernel"], desc, n_local, peaks_desc, not args.no_pipelined_mix, experiment)
-        if t:
-            result["roofline"]["traffic"] = float(t[0])  # bytes per launch
-            result["roofline"]["traffic_source"] = "profiles/" + t[1] + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command; FETCH x2 on gfx950)"
+        result["config"]["lib_sha16"] = lib_sha16()
+        achieved = result["roofline"]["achieved"] * 1e9
 
     # ---- extras on one GPU ------------------------------------------------------------------------------------------
     extras = rank == 0 and world == 1 and not args.no_extras
@@ -489,7 +542,7 @@ def main():
             r2 = Runner(env, ord_flags, n_local, 1)
             g2, w2, _ = r2.timed(200, 20)
             p2 = r2.marked(32)
-            result["ordered"] = {"ms_per_step": g2 / 200, "value": n_local * frames * 200 / (g2 * 1e-3), "wall_ms_per_step": w2 / 200, "kernel_us": p2["kernel_ms"] / max(p2["launches"], 1) * 1e3, "steps": 200, "what": "no GAS_FLAG_PIPELINED_MIX: DSP kernel + k_mix_reduce per callback, as a synchronous audio callback runs; peaks: " + peaks_desc}
+            result["ordered"] = {"ms_per_step": g2 / 200, "value": n_local * frames * 200 / (g2 * 1e-3), "wall_ms_per_step": w2 / 200, "kernel_us": p2["kernel_ms"] / max(p2["launches"], 1) * 1e3, "steps": 200, "what": "no GAS_FLAG_PIPELINED_MIX: one DSP launch per callback and its sum complete in stream order -- what the plugin's synchronous mix() runs; peaks: " + peaks_desc, "roofline": roofline_entry(p2, n_local, desc, peaks_desc, False, "")}
             lat = {"sources": n_local, **r2.latency(256)}
             r2.close()
             del r2
@@ -497,20 +550,27 @@ def main():
                 r5 = Runner(env, head_flags & ~K.FLAG_BATCHED_LAUNCH, n_local, args.reduce_bucket)
                 g5, w5, _ = r5.timed(200, 20)
                 p5 = r5.marked(32)
-                result["unbatched"] = {"ms_per_step": g5 / 200, "value": n_local * frames * 200 / (g5 * 1e-3), "wall_ms_per_step": w5 / 200, "kernel_us": p5["kernel_ms"] / max(p5["launches"], 1) * 1e3, "kernel": p5["kernel"], "steps": 200, "what": "throughput mode without GAS_FLAG_BATCHED_LAUNCH: GAS_FLAG_PIPELINED_MIX only, one k_hrtf_uni launch per callback (round 1's headline arrangement)"}
+                result["unbatched"] = {"ms_per_step": g5 / 200, "value": n_local * frames * 200 / (g5 * 1e-3), "wall_ms_per_step": w5 / 200, "kernel_us": p5["kernel_ms"] / max(p5["launches"], 1) * 1e3, "kernel": p5["kernel"], "steps": 200, "what": "throughput mode without GAS_FLAG_BATCHED_LAUNCH: GAS_FLAG_PIPELINED_MIX only, one k_hrtf_uni launch per callback (round 1's headline arrangement)", "roofline": roofline_entry(p5, n_local, desc, peaks_desc, True, "--no-batched-launch")}
                 r5.close()
                 del r5
             if kind == 2 and not args.exact_peaks:
                 r3 = Runner(env, 0, n_local, 1)
                 g3, w3, _ = r3.timed(200, 20)
                 p3 = r3.marked(32)
-                result["exact_peaks"] = {"ms_per_step": g3 / 200, "value": n_local * frames * 200 / (g3 * 1e-3), "kernel_us": p3["kernel_ms"] / max(p3["launches"], 1) * 1e3, "steps": 200, "what": "ordered mode, exact output peak of every source (no GAS_FLAG_PEAKS_DRAINING_ONLY): the reference's per-playback peak computed for all"}
+                result["exact_peaks"] = {"ms_per_step": g3 / 200, "value": n_local * frames * 200 / (g3 * 1e-3), "kernel_us": p3["kernel_ms"] / max(p3["launches"], 1) * 1e3, "steps": 200, "what": "ordered mode, exact output peak of every source (no GAS_FLAG_PEAKS_DRAINING_ONLY): the reference's per-playback peak computed for all", "roofline": roofline_entry(p3, n_local, desc, "every source", False, "")}
                 r3.close()
                 del r3
             result["latency"] = {"what": "one synchronous callback at a time (device-resident parameter publish every second callback + gas_process_block + gas_ctx_synchronize), ordered mode, host clock", "budget_ms": frames / 48000.0 * 1e3, "runs": [lat]}
             if args.workload == "hrtf" and n_local == 8192:
                 r4 = Runner(env, ord_flags, 10240, 1)  # the north star's ">= 10^4 sources inside one callback", stated directly
                 result["latency"]["runs"].append({"sources": 10240, **r4.latency(256)})
+                g4, _, _ = r4.timed(200, 20)
+                p4 = r4.marked(32)
+                desc4 = WORKLOADS[args.workload][5] + " -- run with 10240 sources/GPU instead"
+                result["roofline_sync"] = [
+                    {"sources": n_local, "ms_per_step": result["ordered"]["ms_per_step"], **result["ordered"]["roofline"]},
+                    {"sources": 10240, "ms_per_step": g4 / 200, **roofline_entry(p4, 10240, desc4, f"draining sources only ({r4.n_draining} of 10240 per GPU)", False, "")},
+                ]
                 r4.close()
                 del r4
             if args.workload == "hrtf" and n_local == 8192:
@@ -558,6 +618,9 @@ def main():
         if not args.no_max_sources and args.workload.startswith("hrtf") and not args.no_extras:
             try:
                 result["max_sources_under_10ms"] = probe_max_sources(gas, synth, torch, kind, chain, frames, hrir, args.dirs)
+                if result["max_sources_under_10ms"] and "roofline" in result["max_sources_under_10ms"] and "roofline_sync" in result:
+                    m = result["max_sources_under_10ms"]
+                    result["roofline_sync"].append({"sources": m["sources"], "ms_per_step": m["p50_callback_ms"], **m["roofline"]})
             except Exception as e:  # the probe must never cost the headline line
                 result["max_sources_under_10ms"] = {"error": str(e)}
         if not args.no_cpu_baseline:
@@ -603,6 +666,15 @@ def probe_max_sources(gas, synth, torch, kind, chain, frames, hrir, dirs, sample
             p99 = float(a[min(len(a) - 1, int(np.ceil(0.99 * len(a))) - 1)])
             if p99 < 10.0:
                 best = {"sources": n, "p50_callback_ms": float(a[len(a) // 2]), "p99_callback_ms": p99, "max_callback_ms": float(a[-1]), "samples": samples}
+                # the synchronous launch of this rung, event-timed inside the library, as a roofline line of its own
+                ctx.profile_enable(1)
+                ctx.profile_read(reset=True)
+                for _ in range(8):
+                    ctx.process_block_raw(src.data_ptr(), None, n, frames, out.data_ptr(), peaks.data_ptr(), 1)
+                torch.cuda.synchronize()
+                prof = ctx.profile_read(reset=True)
+                ctx.profile_enable(0)
+                best["roofline"] = roofline_entry(prof, n, WORKLOADS["hrtf"][5] + f" -- run with {n} sources/GPU instead", f"draining sources only (0 of {n} per GPU)", False, "")
             else:
                 break
         del src, out, peaks

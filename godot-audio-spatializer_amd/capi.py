@@ -84,6 +84,9 @@ class Profile(C.Structure):
         ("kernel_ms", C.c_double),
         ("bytes_per_launch", C.c_uint64),
         ("kernel_name", C.c_char * 64),
+        ("callbacks_per_launch", C.c_uint32),
+        ("reserved", C.c_uint32),
+        ("bytes_per_callback_formula", C.c_uint64),
     ]
 
 
@@ -476,7 +479,7 @@ class SpatializerContext:
     def profile_read(self, reset=True):
         p = Profile()
         self._check(self.lib.gas_profile_read(self.h, C.byref(p), int(reset)), "gas_profile_read")
-        return {"launches": p.launches, "kernel_ms": p.kernel_ms, "bytes_per_launch": p.bytes_per_launch, "kernel": p.kernel_name.decode()}
+        return {"launches": p.launches, "kernel_ms": p.kernel_ms, "bytes_per_launch": p.bytes_per_launch, "kernel": p.kernel_name.decode(), "callbacks_per_launch": p.callbacks_per_launch, "bytes_per_callback_formula": p.bytes_per_callback_formula}
 
 
 class BatchedSpatializerHost:

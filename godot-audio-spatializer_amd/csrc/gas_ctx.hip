@@ -204,7 +204,8 @@ struct gas_ctx {
 	uint32_t ev_used = 0;
 	uint64_t prof_launches = 0;
 	double prof_ms = 0.0;
-	uint64_t prof_bytes = 0;
+	uint64_t prof_bytes = 0, prof_bytes_formula = 0;
+	uint32_t prof_k = 1;
 	int prof_group = -1;
 	bool prof_uni = false; // the timed launch was k_hrtf_uni
 	bool prof_pipe = false; // the timed launch was k_biquad_pipe
@@ -678,6 +679,7 @@ int run_groups(gas_ctx *c, const gas_audio_frame *d_src, const uint32_t *d_slots
 			GAS_HIP(c, hipEventRecord(c->ev[c->ev_used + 1], c->stream));
 			c->ev_used += 2;
 			c->prof_bytes = group_bytes(c, gt, gr.count) + carried_bytes;
+			c->prof_k = 1;
 			if ((gt == G_FX_HRTF || gt == G_FX_ER_HRTF) && groups[gt + 1].count > 0) {
 				// the exact-peak sources ride in the same launch: add their per-source bytes (table/mix terms counted once)
 				c->prof_bytes += group_bytes(c, gt + 1, groups[gt + 1].count) - group_bytes(c, gt + 1, 0);
@@ -836,7 +838,22 @@ int run_hrtf_batch(gas_ctx *c, const std::vector<gas_ctx::Deferred> &blocks, uin
 	if (timed) {
 		GAS_HIP(c, hipEventRecord(c->ev[c->ev_used + 1], c->stream));
 		c->ev_used += 2;
-		c->prof_bytes = (uint64_t)K * group_bytes(c, G_FX_HRTF, n) + carried_bytes;
+		// What this launch has to move (not K times the single-callback formula: k_hrtf_multi<., true> reads a history
+		// row in its first block and writes it back in its last one, and meets the HRIR table once): per block the
+		// frames, 8 B of peak per source, 8 B of (gain, direction) where the block has device-published rows, and the
+		// workgroups' partial mix is not counted (round 2 did not either); once per launch the previous gain (r + w)
+		// and the table; the history once in and once out, or per block when it cannot stay in LDS.
+		{
+			const uint64_t hist_rw = 2ull * c->hist_len * 4;
+			const bool hist_lds = gas_hrtf_multi_hist_in_lds(n, F);
+			uint64_t fresh_blocks = 0;
+			for (uint32_t b = 0; b < K; b++) {
+				fresh_blocks += blocks[b].fresh ? 1 : 0;
+			}
+			c->prof_bytes = (uint64_t)K * n * (F * 8 + 8) + fresh_blocks * n * 8 + (uint64_t)n * 8 + (hist_lds ? 1ull : (uint64_t)K) * n * hist_rw + (uint64_t)c->tab.dirs * 2 * GAS_HRTF_TAPS * 4 + (uint64_t)K * c->cfg.channel_count * F * 8 + carried_bytes;
+		}
+		c->prof_bytes_formula = (uint64_t)K * group_bytes(c, G_FX_HRTF, n) + carried_bytes;
+		c->prof_k = K;
 		c->prof_group = G_FX_HRTF;
 		c->prof_uni = false;
 		c->prof_pipe = false;
@@ -2603,6 +2620,8 @@ int gas_profile_read(gas_ctx *c, gas_profile *out, int reset) {
 	out->launches = c->prof_launches;
 	out->kernel_ms = c->prof_ms;
 	out->bytes_per_launch = c->prof_bytes;
+	out->callbacks_per_launch = c->prof_k;
+	out->bytes_per_callback_formula = c->prof_k > 1 ? c->prof_bytes_formula : c->prof_bytes;
 	if (c->prof_group >= 0) {
 		std::string name = c->prof_multi ? "k_hrtf_multi" : (c->prof_uni ? "k_hrtf_uni" : k_group_kernel[c->prof_group]);
 		if (c->prof_pipe && name.rfind("k_biquad_mix", 0) == 0) {

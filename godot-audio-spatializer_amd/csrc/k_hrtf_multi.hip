@@ -22,7 +22,7 @@
 // launch (10.65 vs 11.15 us per block, profiles/r02_notes.md).  The single-block kernels show no difference.
 #define GAS_USE_NT 1
 #ifndef GAS_MULTI_L2_PREFETCH
-#define GAS_MULTI_L2_PREFETCH 1 // touch the rows of the source two trips ahead (one dword per 128-byte line)
+#define GAS_MULTI_L2_PREFETCH 0 // EXPERIMENT (off): touch the rows of the source two trips ahead, one dword per 128-byte line.  Measured SLOWER (8192 sources: 12.0 vs 11.2 us per block; 65536: 87.7 vs 75.1): the launch is bound by what the fabric moves, not by one wave's load latency, and the touches add L2 -> L1 traffic (profiles/r03_notes.md)
 #endif
 #include "gas_hrtf_wave.h"
 
@@ -345,6 +345,21 @@ __global__ __launch_bounds__(MW * 64, GAS_HRTF_WAVES_PER_SIMD) void k_hrtf_multi
 }
 
 } // namespace
+
+bool gas_hrtf_multi_hist_in_lds(uint32_t n, uint32_t frames) {
+	const uint32_t wgs = gas_hrtf_uni_partials(n);
+	const uint32_t per_wave = (n + wgs * MW - 1) / (wgs * MW);
+	switch (frames / 128) {
+		case 1:
+			return per_wave <= (uint32_t)MultiLds<1>::HIST_ROWS;
+		case 2:
+			return per_wave <= (uint32_t)MultiLds<2>::HIST_ROWS;
+		case 3:
+			return per_wave <= (uint32_t)MultiLds<3>::HIST_ROWS;
+		default:
+			return per_wave <= (uint32_t)MultiLds<4>::HIST_ROWS;
+	}
+}
 
 hipError_t gas_launch_hrtf_multi(hipStream_t stream, const gas_group_args &g, const gas_hrtf_blocks &mb, const uint32_t *peak_bits, bool peak_all, const gas_dev_state &st, const gas_hrtf_table &tab, const float2 *twiddles, uint32_t frames, uint32_t hist_len, float *partials) {
 	if (g.n == 0 || mb.k == 0) {

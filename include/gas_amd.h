@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define GAS_ABI_VERSION 1
+#define GAS_ABI_VERSION 2 /* 2: gas_profile grew (callbacks_per_launch, bytes_per_callback_formula); pause / position / effect kinds */
 
 /* audio_spatializer.h:47-52 */
 #define GAS_MAX_CHANNELS_PER_BUS 4
@@ -171,8 +171,14 @@ typedef struct gas_params {
 typedef struct gas_profile {
 	uint64_t launches; /* timed launches of the dominant kernel since the last reset */
 	double kernel_ms; /* sum of their durations */
-	uint64_t bytes_per_launch; /* algorithmic bytes of the last launch (SURVEY.md 8d formula) */
+	uint64_t bytes_per_launch; /* bytes the last timed launch had to move: SURVEY.md 8d's per-callback
+	                            * formula for a one-callback launch; for a launch of K callbacks (GAS_FLAG_BATCHED_LAUNCH)
+	                            * K x (frames + per-block parameters / peaks + partial mix) + the history rows once in and
+	                            * once out when they stay in LDS between blocks (K times otherwise) + the HRIR table once */
 	char kernel_name[64];
+	uint32_t callbacks_per_launch; /* K of the last timed launch (1 unless batched) */
+	uint32_t reserved;
+	uint64_t bytes_per_callback_formula; /* SURVEY.md 8d's per-callback figure x K: what round 2 reported for batched launches */
 } gas_profile;
 
 /* ---- context ---------------------------------------------------------- */

@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol(gas):
     missing = [f for f in declared if not hasattr(lib, f)]
     assert not missing, missing
     assert sorted(gas.capi.EXPORTS) == declared  # the Python binding lists exactly the header's surface
-    assert lib.gas_abi_version() == 1
+    assert lib.gas_abi_version() == 2
 
 
 def test_pod_layouts(gas):

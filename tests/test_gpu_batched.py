@@ -216,3 +216,78 @@ def test_batched_launch_random_event_sequences(gas, seed):
     assert not np.isnan(base).any()
     assert np.array_equal(base, got), f"seed {seed}: n {n} F {F} T {T} depth {depth} events {events}"
     assert np.array_equal(pk0, pk1)
+
+
+def test_batched_launch_against_the_oracle(gas, ob):
+    """The headline kernel compared with the oracle directly (not through k_hrtf_uni): depth 10, device-published rows
+    taking effect at some blocks, draining sources (exact peaks), a join in the middle of a batch, and a list that
+    gains a playback mid-run (a second oracle starts there; the mixes add).  Every callback's mix within 1e-5 relative
+    RMS, the draining sources' peaks within 2e-5."""
+    import torch
+
+    from godot_audio_spatializer_amd import synth
+    from helpers import TOL, rel_rms
+
+    K = gas.capi
+    n, F, T, dirs = 3000, 512, 26, 48
+    rng = np.random.default_rng(101)
+    hrir = synth.synthetic_hrir(np.random.default_rng(7), dirs=dirs)
+    publish_at = {3, 4, 11, 12, 20}  # callbacks in front of which device-resident parameter rows are published
+    join_at, grow_at = 13, 17
+    with gas.SpatializerContext(max_sources=n + 4, frames=F, flags=K.FLAG_PEAKS_DRAINING_ONLY | K.FLAG_PIPELINED_MIX | K.FLAG_BATCHED_LAUNCH) as ctx:
+        ctx.hrtf_load(hrir)
+        ctx.set_batch_depth(10)
+        slots = ctx.source_alloc_many(n, K.KIND_EFFECT, (K.FX_HRTF,))
+        draining = np.arange(0, n, 11)
+        for s in draining:
+            ctx.source_set_draining(int(slots[s]), True)
+        params = synth.draw_params(rng, n, dirs=dirs, frames=F)
+        ctx.params_publish_batch(slots, params)
+        ora = ob.BatchOracle(ob.KIND_EFFECT, n, F, chain=[K.FX_HRTF], hrir=hrir)
+        extra_ora, extra_params = None, None
+        outs = torch.full((T, 1, F, 2), float("nan"), device="cuda")
+        peaks = torch.zeros(T, n + 1, 2, device="cuda")
+        keep, want, want_pk = [], [], []
+        torch.cuda.synchronize()
+        cur_n, first = n, True
+        for t in range(T):
+            if t == grow_at:  # one more playback joins the list (newest first in the reference; any order here)
+                new = ctx.source_alloc(K.KIND_EFFECT, (K.FX_HRTF,))
+                extra_params = synth.draw_params(rng, 1, dirs=dirs, frames=F)
+                ctx.params_publish(new, extra_params)
+                slots = np.append(slots, np.uint32(new))
+                extra_ora = ob.BatchOracle(ob.KIND_EFFECT, 1, F, chain=[K.FX_HRTF], hrir=hrir)
+                cur_n, first = n + 1, True
+            if t in publish_at:
+                p = synth.draw_params(rng, cur_n, dirs=dirs, frames=F)
+                d_p = torch.from_numpy(p.view(np.uint8).reshape(cur_n, -1).copy()).cuda()
+                keep.append(d_p)
+                torch.cuda.synchronize()
+                if first:
+                    ctx.params_publish_batch(slots, p)  # the device form addresses the previous callback's list
+                else:
+                    ctx.params_publish_device(d_p.data_ptr(), cur_n)
+                params = p[:n]
+                if cur_n > n:
+                    extra_params = p[n:]
+            if t == join_at:
+                ctx.join_outputs()
+            src = synth.draw_sources(rng, cur_n, F)
+            d_src = torch.from_numpy(src).cuda()
+            keep.append(d_src)
+            torch.cuda.synchronize()
+            rc = ctx.process_block_raw(d_src.data_ptr(), slots if first else None, cur_n, F, outs[t].data_ptr(), peaks[t].data_ptr(), K.MEM_DEVICE)
+            assert rc == 0
+            first = False
+            _, rp, r64 = ora.block(params.astype(ob.PARAMS_DTYPE), src[:n], want64=True)
+            if extra_ora is not None:
+                _, rp1, e64 = extra_ora.block(extra_params.astype(ob.PARAMS_DTYPE), src[n:], want64=True)
+                r64 = r64 + e64
+            want.append(r64)
+            want_pk.append(rp)
+        ctx.synchronize()
+        got, got_pk = outs.cpu().numpy(), peaks.cpu().numpy()
+    for t in range(T):
+        assert rel_rms(got[t][0], want[t][0]) <= TOL, f"callback {t}"
+        np.testing.assert_allclose(got_pk[t][draining], want_pk[t][draining], rtol=2e-5, atol=1e-7, err_msg=f"callback {t}")
+        assert np.all(np.isposinf(np.delete(got_pk[t][:n], draining, axis=0)))

@@ -234,3 +234,53 @@ def test_bus_call_reuses_the_list(gas):
         ctx2.synchronize()
     a, b = out[0].cpu().numpy(), out[1].cpu().numpy()
     assert np.array_equal(a, b) and np.abs(a[1]).max() > 0
+
+
+@pytest.mark.parametrize("peaks_mode", ["every_source", "draining_only"])
+def test_fused_two_bus_form_bus_sums_against_the_oracle_at_size(gas, ob, peaks_mode):
+    """k_hrtf_uni<BUS2> at a size where per-source oracles are too slow: bus b's mix is linear in each source's gain, so
+    the expectation for (bus, ear) is ONE batch oracle whose gains are scaled by every source's weight on that bus
+    and ear (routes held constant over the callbacks, so the scaled previous gains stay consistent).  Peaks are the
+    unscaled oracle's (the gate sees y, not a bus) -- for every source, or for the draining ones only."""
+    from godot_audio_spatializer_amd import synth
+
+    K = gas.capi
+    n, F, dirs, n_buses = 2304 + 77, 512, 40, 2
+    rng = np.random.default_rng(21)
+    hrir = synth.synthetic_hrir(np.random.default_rng(7), dirs=dirs)
+    routes = np.zeros(n, K.BUS_ROUTE_DTYPE)
+    routes["dry_bus"] = rng.integers(0, n_buses, n)
+    routes["send_bus"] = np.where(rng.uniform(size=n) < 0.7, rng.integers(0, n_buses, n), K.BUS_NONE)
+    routes["send"][:, 0, :] = rng.uniform(0.0, 1.2, (n, 2)).astype(np.float32)
+    w = np.zeros((n_buses, 2, n), np.float32)  # weight of source s on (bus, ear)
+    for b in range(n_buses):
+        for ear in range(2):
+            w[b, ear] = (routes["dry_bus"] == b) + np.where(routes["send_bus"] == b, routes["send"][:, 0, ear], 0.0)
+    flags = K.FLAG_PEAKS_DRAINING_ONLY if peaks_mode == "draining_only" else 0
+    draining = np.arange(0, n, 29)
+    plain = ob.BatchOracle(ob.KIND_EFFECT, n, F, chain=[K.FX_HRTF], hrir=hrir)
+    scaled = [[ob.BatchOracle(ob.KIND_EFFECT, n, F, chain=[K.FX_HRTF], hrir=hrir) for _ in range(2)] for _ in range(n_buses)]
+    with gas.SpatializerContext(max_sources=n, frames=F, flags=flags) as ctx:
+        ctx.hrtf_load(hrir)
+        slots = ctx.source_alloc_many(n, K.KIND_EFFECT, (K.FX_HRTF,))
+        if peaks_mode == "draining_only":
+            for s in draining:
+                ctx.source_set_draining(int(slots[s]), True)
+        ctx.bus_routes_publish(slots, routes)
+        for cb in range(3):
+            p = synth.draw_params(rng, n, dirs=dirs, frames=F)
+            ctx.params_publish_batch(slots, p)
+            src = synth.draw_sources(rng, n, F)
+            got, peaks = ctx.process_block_buses(src, slots, n_buses)
+            _, wpeaks, _ = plain.block(p.astype(ob.PARAMS_DTYPE), src)
+            if peaks_mode == "every_source":
+                np.testing.assert_allclose(peaks, wpeaks, rtol=3e-5, atol=1e-7)
+            else:
+                np.testing.assert_allclose(peaks[draining], wpeaks[draining], rtol=3e-5, atol=1e-7)
+                assert np.all(np.isposinf(np.delete(peaks, draining, axis=0)))
+            for b in range(n_buses):
+                for ear in range(2):
+                    q = p.copy()
+                    q["hrtf_gain"] = (p["hrtf_gain"] * w[b, ear]).astype(np.float32)
+                    _, _, y64 = scaled[b][ear].block(q.astype(ob.PARAMS_DTYPE), src, want64=True)
+                    assert rel_rms(got[b, 0, :, ear], y64[0, :, ear]) <= TOL, (cb, b, ear)

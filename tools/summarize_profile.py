@@ -48,6 +48,8 @@ def write_pmc_json(out, path):
         "peaks": line["config"].get("peaks"),
         "pipelined_mix": bool(line["config"].get("pipelined_mix", False)),
         "experiment": line["config"].get("experiment", ""),
+        "lib_sha16": line["config"].get("lib_sha16"),
+        "callbacks_per_launch": line["roofline"].get("callbacks_per_launch", 1),
         "fetch_size_kib_raw": fetch,
         "write_size_kib_raw": write,
         "fetch_correction": 2.0,
@@ -85,10 +87,10 @@ def main(out):
             print(f"{k[:70]:70s} dispatches={n:6d} avg={s / n:14.1f} KiB")
 
 
-def sq_summary(out):
-    """Per-dispatch averages of the SQ pass for the library's kernels (quad-cycle units, MI355X_MICROARCH.md)."""
-    cc = find(os.path.join(out, "sq"), "*counter_collection.csv")
-    print("== rocprofv3 --pmc SQ_* (per-dispatch average) ==")
+def sq_summary(out, sub="sq", title="SQ_* (per-dispatch average)"):
+    """Per-dispatch averages of an SQ pass for the library's kernels (quad-cycle units, MI355X_MICROARCH.md)."""
+    cc = find(os.path.join(out, sub), "*counter_collection.csv")
+    print(f"== rocprofv3 --pmc {title} ==")
     if not cc:
         print("missing")
         return
@@ -121,6 +123,7 @@ def bench_line(out):
 if __name__ == "__main__":
     main(sys.argv[1])
     sq_summary(sys.argv[1])
+    sq_summary(sys.argv[1], "insts", "SQ_INSTS_* (wave-level instructions per dispatch, average)")
     bench_line(sys.argv[1])
     if len(sys.argv) > 2:
         write_pmc_json(sys.argv[1], sys.argv[2])
