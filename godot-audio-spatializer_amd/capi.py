@@ -20,6 +20,10 @@ KIND_EFFECT = 2
 FX_HIGHSHELF = 1
 FX_EARLY_REFLECTIONS = 2
 FX_HRTF = 3
+FX_LOWPASS, FX_HIGHPASS, FX_BANDPASS, FX_NOTCH, FX_LOWSHELF, FX_AMPLIFY = 4, 5, 6, 7, 8, 9
+MAX_EFFECTS = 4
+# gas_fx_settings: settings of the engine-effect kinds by chain position (64 bytes)
+FX_SETTINGS_DTYPE = np.dtype([("filter_cutoff_hz", np.float32, (MAX_EFFECTS,)), ("filter_resonance", np.float32, (MAX_EFFECTS,)), ("filter_gain", np.float32, (MAX_EFFECTS,)), ("amplify_volume_db", np.float32, (MAX_EFFECTS,))])
 MEM_HOST = 0
 MEM_DEVICE = 1
 FLAG_PEAKS_DRAINING_ONLY = 1
@@ -112,8 +116,17 @@ SPAT3D_CONFIG_DTYPE = np.dtype(
 )
 POSE_DTYPE = np.dtype([("position", np.float32, (3,)), ("volume_db", np.float32), ("velocity", np.float32, (3,)), ("max_db", np.float32), ("forward", np.float32, (3,)), ("pitch_scale", np.float32)])
 AREA_SEND_DTYPE = np.dtype([("using_reverb_bus", np.uint32), ("reverb_uniformity", np.float32), ("reverb_amount", np.float32), ("present", np.uint32)])
-BUS_ROUTE_DTYPE = np.dtype([("dry_bus", np.uint32), ("send_bus", np.uint32), ("send", np.float32, (MAX_CHANNELS, 2))])
+MAX_MORE_SENDS = 4
+BUS_ROUTE_DTYPE = np.dtype([("dry_bus", np.uint32), ("send_bus", np.uint32), ("send", np.float32, (MAX_CHANNELS, 2)), ("more_bus", np.uint32, (MAX_MORE_SENDS,)), ("more_send", np.float32, (MAX_MORE_SENDS, MAX_CHANNELS, 2))])
 BUS_NONE = 0xFFFFFFFF
+
+
+def bus_routes(n):
+    """n default routes: dry bus 0, no sends (gas_bus_route with every send slot GAS_BUS_NONE)."""
+    r = np.zeros(n, BUS_ROUTE_DTYPE)
+    r["send_bus"] = BUS_NONE
+    r["more_bus"] = BUS_NONE
+    return r
 LISTENER_DTYPE = np.dtype([("basis", np.float32, (3, 3)), ("origin", np.float32, (3,)), ("velocity", np.float32, (3,)), ("pad", np.float32)])
 assert SPAT3D_CONFIG_DTYPE.itemsize == 64 and POSE_DTYPE.itemsize == 48 and LISTENER_DTYPE.itemsize == 64
 
@@ -150,12 +163,15 @@ EXPORTS = [
     "gas_source_reset",
     "gas_source_set_draining",
     "gas_params_publish",
+    "gas_fx_settings_publish",
     "gas_params_publish_batch",
     "gas_hrtf_load",
     "gas_calc_spatialization",
     "gas_calc_spatialization_areas",
     "gas_stream_create",
     "gas_stream_destroy",
+    "gas_stream_get_info",
+    "gas_stream_positions",
     "gas_stream_set_resampled",
     "gas_source_bind_stream",
     "gas_process_block_streams",
@@ -226,10 +242,13 @@ def load_library():
     L.gas_source_reset.argtypes = [vp, u32]
     L.gas_source_set_draining.argtypes = [vp, u32, i32]
     L.gas_params_publish.argtypes = [vp, u32, vp]
+    L.gas_fx_settings_publish.argtypes = [vp, vp, vp, u32]
     L.gas_params_publish_batch.argtypes = [vp, vp, vp, u32, i32]
     L.gas_hrtf_load.argtypes = [vp, vp, u32, u32]
     L.gas_stream_create.argtypes = [vp, vp, i32, u32, C.c_uint64, C.POINTER(u32)]
     L.gas_stream_destroy.argtypes = [vp, u32]
+    L.gas_stream_positions.argtypes = [vp, u32, vp]
+    L.gas_stream_get_info.argtypes = [vp, u32, C.POINTER(C.c_uint64), C.POINTER(u32), C.POINTER(i32)]
     L.gas_stream_set_resampled.argtypes = [vp, u32, i32]
     L.gas_source_bind_stream.argtypes = [vp, u32, u32, C.c_uint64]
     L.gas_process_block_streams.argtypes = [vp, vp, u32, u32, vp, vp, vp, i32]
@@ -318,6 +337,18 @@ class SpatializerContext:
         p = np.ascontiguousarray(params, dtype=PARAMS_DTYPE).reshape(1)
         self._check(self.lib.gas_params_publish(self.h, int(slot), _np_ptr(p)), "gas_params_publish")
 
+    @staticmethod
+    def fx_settings_defaults(n):
+        d = np.zeros(n, FX_SETTINGS_DTYPE)
+        d["filter_cutoff_hz"], d["filter_resonance"], d["filter_gain"] = 2000.0, 0.5, 1.0
+        return d
+
+    def fx_settings_publish(self, slots, settings):
+        s = np.ascontiguousarray(slots, dtype=np.uint32)
+        f = np.ascontiguousarray(settings, dtype=FX_SETTINGS_DTYPE)
+        assert s.shape == f.shape
+        self._check(self.lib.gas_fx_settings_publish(self.h, _np_ptr(s), _np_ptr(f), len(s)), "gas_fx_settings_publish")
+
     def params_publish_batch(self, slots, params):
         s = np.ascontiguousarray(slots, dtype=np.uint32)
         p = np.ascontiguousarray(params, dtype=PARAMS_DTYPE)
@@ -395,6 +426,15 @@ class SpatializerContext:
         h = np.ascontiguousarray(hrir, dtype=np.float32)
         assert h.ndim == 3 and h.shape[1] == 2
         self._check(self.lib.gas_hrtf_load(self.h, _np_ptr(h), h.shape[0], h.shape[2]), "gas_hrtf_load")
+
+    def hrtf_load_positions(self, positions, hrir, az_steps, el_steps, interpolation=0):
+        """positions [m][2] (azimuth, elevation) radians, hrir [m][2][taps]; returns the gridded set [dirs][2][256]."""
+        pos = np.ascontiguousarray(positions, dtype=np.float32)
+        h = np.ascontiguousarray(hrir, dtype=np.float32)
+        assert pos.ndim == 2 and pos.shape[1] == 2 and h.ndim == 3 and h.shape[:2] == (pos.shape[0], 2)
+        out = np.zeros((az_steps * el_steps, 2, HRTF_TAPS), np.float32)
+        self._check(self.lib.gas_hrtf_load_positions(self.h, _np_ptr(pos), _np_ptr(h), pos.shape[0], h.shape[2], az_steps, el_steps, int(interpolation), _np_ptr(out)), "gas_hrtf_load_positions")
+        return out
 
     # ---- hot path ----
     def process_block(self, src, slots):
@@ -501,7 +541,15 @@ class BatchedSpatializerHost:
         L.gas_host_set_playback_disable_threshold_db.restype = None
         L.gas_host_is_playback_active.argtypes = [vp, u32]
         L.gas_host_playback_count.argtypes = [vp]
+        L.gas_host_set_playback_paused.argtypes = [vp, u32, i32]
+        L.gas_host_is_playback_paused.argtypes = [vp, u32]
+        L.gas_host_get_playback_position.argtypes = [vp, u32, C.POINTER(C.c_uint64)]
         L.gas_host_get_mixed_frames.argtypes = [vp, i32, vp, i32]
+        L.gas_host_set_release_fn.argtypes = [vp, vp, vp]
+        L.gas_host_collect_released.argtypes = [vp]
+        L.gas_host_set_process_effects_fn.argtypes = [vp, vp, vp]
+        L.gas_host_start_playback.argtypes = [vp, vp, vp, C.POINTER(u32)]
+        self._callbacks = []  # ctypes trampolines must outlive their registration
         fx = (C.c_int32 * max(1, len(effects)))(*effects)
         h = C.c_void_p()
         ctx._check(L.gas_host_create(ctx.h, kind, fx, len(effects), C.byref(h)), "gas_host_create")
@@ -525,18 +573,73 @@ class BatchedSpatializerHost:
         self.ctx._check(self.lib.gas_host_start_playback_device_stream(self.h, int(stream_id), int(start_frame), C.byref(pid)), "gas_host_start_playback_device_stream")
         return pid.value
 
+    STREAM_MIX_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_int)
+    RELEASE_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_uint32, C.c_void_p)
+    PROCESS_EFFECTS_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint32, C.c_void_p)
+
+    def start_playback(self, mix, user=0):
+        """mix(buffer: float32 [frames, 2] view, rate_scale, frames) -> frames mixed: the engine's
+        AudioStreamPlayback::mix as a Python callable (tests only; it runs on whichever thread mixes)."""
+
+        def tramp(u, buf, rate, frames):
+            view = np.ctypeslib.as_array(C.cast(buf, C.POINTER(C.c_float)), shape=(frames, 2))
+            return int(mix(view, rate, frames))
+
+        cb = self.STREAM_MIX_FN(tramp)
+        self._callbacks.append(cb)
+        pid = C.c_uint32()
+        self.ctx._check(self.lib.gas_host_start_playback(self.h, C.cast(cb, C.c_void_p), C.c_void_p(user), C.byref(pid)), "gas_host_start_playback")
+        return pid.value
+
+    def set_release_fn(self, fn):
+        """fn(id, user) for every playback the host has finished with (control thread)."""
+        cb = self.RELEASE_FN(lambda _u, pid, user: fn(pid, user or 0)) if fn else None
+        self._callbacks.append(cb)
+        return self.lib.gas_host_set_release_fn(self.h, C.cast(cb, C.c_void_p) if cb else None, None)
+
+    def collect_released(self):
+        return self.lib.gas_host_collect_released(self.h)
+
+    def set_process_effects_fn(self, fn):
+        """fn(id, params: one-element PARAMS_DTYPE view) -> truthy when it edited the row (audio thread)."""
+
+        def tramp(_u, pid, p):
+            row = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(PARAMS_DTYPE.itemsize,)).view(PARAMS_DTYPE)
+            return int(bool(fn(pid, row)))
+
+        cb = self.PROCESS_EFFECTS_FN(tramp) if fn else None
+        self._callbacks.append(cb)
+        return self.lib.gas_host_set_process_effects_fn(self.h, C.cast(cb, C.c_void_p) if cb else None, None)
+
     def stop_playback(self, pid):
         return self.lib.gas_host_stop_playback(self.h, pid)
 
     def set_spatializer_parameters(self, pid, params):
+        """Returns GAS_OK, or GAS_ERR_BAD_SLOT when the playback has ended and been reaped meanwhile (not an error for a
+        control thread: the reference's update_spatializer_parameters has nothing to address then either)."""
         p = np.ascontiguousarray(params, dtype=PARAMS_DTYPE).reshape(1)
-        self.ctx._check(self.lib.gas_host_set_spatializer_parameters(self.h, pid, _np_ptr(p)), "gas_host_set_spatializer_parameters")
+        rc = self.lib.gas_host_set_spatializer_parameters(self.h, pid, _np_ptr(p))
+        if rc != -3:
+            self.ctx._check(rc, "gas_host_set_spatializer_parameters")
+        return rc
 
     def is_playback_active(self, pid):
         return bool(self.lib.gas_host_is_playback_active(self.h, pid))
 
     def playback_count(self):
         return self.lib.gas_host_playback_count(self.h)
+
+    def set_playback_paused(self, pid, paused=True):
+        return self.lib.gas_host_set_playback_paused(self.h, pid, int(paused))
+
+    def is_playback_paused(self, pid):
+        return bool(self.lib.gas_host_is_playback_paused(self.h, pid))
+
+    def get_playback_position(self, pid):
+        """Frames of the stream consumed so far (0 for an unknown id)."""
+        f = C.c_uint64()
+        self.lib.gas_host_get_playback_position(self.h, pid, C.byref(f))
+        return f.value
 
     def get_mixed_frames(self, channel, frame_count):
         out = np.full((frame_count, 2), np.nan, dtype=np.float32)

@@ -44,4 +44,87 @@ __device__ inline Coeffs highshelf_coeffs(float sampling_rate, float cutoff_hz, 
 	return c;
 }
 
+// [ENGINE] AudioFilterSW::prepare_coefficients for the other modes AudioEffectFilter's subclasses select (recollection
+// of servers/audio/audio_filter_sw.cpp, unpinned like the rest of SURVEY.md Appendix B): LOWPASS, HIGHPASS, BANDPASS
+// (Q doubled), NOTCH, LOWSHELF; one stage (FILTER_6DB).  Same shape as above: f64 arithmetic, members stored f32, then
+// normalised by a0 with the feedback terms negated.
+__device__ inline Coeffs filter_coeffs(int kind, float sampling_rate, float cutoff_hz, float resonance, float gain_lin) {
+	int sr_limit = (int)(sampling_rate / 2) + 512;
+	double final_cutoff = ((double)cutoff_hz > sr_limit) ? (double)sr_limit : (double)cutoff_hz;
+	if (final_cutoff < 1) {
+		final_cutoff = 1;
+	}
+	double omega = 6.2831853071795864769252867666 * final_cutoff / (double)sampling_rate;
+	double sin_v = sin(omega);
+	double cos_v = cos(omega);
+	double Q = resonance;
+	if (Q <= 0.0) {
+		Q = 0.0001;
+	}
+	if (kind == GAS_FX_BANDPASS) {
+		Q *= 2.0;
+	}
+	double tmpgain = gain_lin;
+	if (tmpgain < 0.001) {
+		tmpgain = 0.001;
+	}
+	double alpha = sin_v / (2 * Q);
+	double a0 = 1.0 + alpha;
+	Coeffs c;
+	switch (kind) {
+		case GAS_FX_LOWPASS:
+			c.b0 = (float)((1.0 - cos_v) / 2.0);
+			c.b1 = (float)(1.0 - cos_v);
+			c.b2 = (float)((1.0 - cos_v) / 2.0);
+			c.a1 = (float)(-2.0 * cos_v);
+			c.a2 = (float)(1.0 - alpha);
+			break;
+		case GAS_FX_HIGHPASS:
+			c.b0 = (float)((1.0 + cos_v) / 2.0);
+			c.b1 = (float)(-(1.0 + cos_v));
+			c.b2 = (float)((1.0 + cos_v) / 2.0);
+			c.a1 = (float)(-2.0 * cos_v);
+			c.a2 = (float)(1.0 - alpha);
+			break;
+		case GAS_FX_BANDPASS:
+			c.b0 = (float)(alpha * sqrt(Q + 1));
+			c.b1 = 0.0f;
+			c.b2 = (float)(-alpha * sqrt(Q + 1));
+			c.a1 = (float)(-2.0 * cos_v);
+			c.a2 = (float)(1.0 - alpha);
+			break;
+		case GAS_FX_NOTCH:
+			c.b0 = 1.0f;
+			c.b1 = (float)(-2.0 * cos_v);
+			c.b2 = 1.0f;
+			c.a1 = (float)(-2.0 * cos_v);
+			c.a2 = (float)(1.0 - alpha);
+			break;
+		default: { // GAS_FX_LOWSHELF
+			double tmpq = sqrt(Q);
+			if (tmpq <= 0) {
+				tmpq = 0.001;
+			}
+			double beta = sqrt(tmpgain) / tmpq;
+			a0 = (tmpgain + 1.0) + (tmpgain - 1.0) * cos_v + beta * sin_v;
+			c.b0 = (float)(tmpgain * ((tmpgain + 1.0) - (tmpgain - 1.0) * cos_v + beta * sin_v));
+			c.b1 = (float)(2.0 * tmpgain * ((tmpgain - 1.0) - (tmpgain + 1.0) * cos_v));
+			c.b2 = (float)(tmpgain * ((tmpgain + 1.0) - (tmpgain - 1.0) * cos_v - beta * sin_v));
+			c.a1 = (float)(-2.0 * ((tmpgain - 1.0) + (tmpgain + 1.0) * cos_v));
+			c.a2 = (float)((tmpgain + 1.0) + (tmpgain - 1.0) * cos_v - beta * sin_v);
+		} break;
+	}
+	c.b0 = (float)((double)c.b0 / a0);
+	c.b1 = (float)((double)c.b1 / a0);
+	c.b2 = (float)((double)c.b2 / a0);
+	c.a1 = (float)((double)c.a1 / (0.0 - a0));
+	c.a2 = (float)((double)c.a2 / (0.0 - a0));
+	return c;
+}
+
+// [ENGINE] Math::db_to_linear (f32 expf of db * ln(10)/20)
+__device__ inline float fx_db_to_linear(float db) {
+	return expf(db * 0.11512925464970228420089957273422f);
+}
+
 } // namespace

@@ -101,7 +101,9 @@ struct gas_ctx {
 
 	std::vector<SlotInfo> slots;
 	std::vector<uint32_t> free_list;
-	std::vector<uint32_t> pending_free;
+	std::vector<uint32_t> pending_free; // audio thread: frees taking effect at the next block boundary
+	std::mutex alloc_mu; // gas_source_alloc / gas_source_free may come from any thread: guards free_list and free_inbox
+	std::vector<uint32_t> free_inbox; // frees requested since the audio thread last looked (adopt_frees)
 	std::vector<uint32_t> stamp; // duplicate detection per block
 	uint32_t stamp_gen = 0;
 
@@ -113,6 +115,11 @@ struct gas_ctx {
 	uint32_t *h_upload_slots = nullptr; // pinned
 	gas_params *d_upload = nullptr;
 	uint32_t *d_upload_slots = nullptr;
+	// gas_fx_settings (engine-effect kinds): host mirror, latest wins, uploaded with the parameters (params_mu)
+	std::vector<gas_fx_settings> h_fxs;
+	std::vector<uint8_t> fx_dirty_flag;
+	std::vector<uint32_t> fx_dirty_list;
+	gas_fx_settings *h_fx_upload = nullptr; // pinned, [max_sources], allocated by the first flush that needs it
 
 	// plain [HRTF] group of the cached list (k_hrtf_uni): which entries need their exact peak
 	uint32_t *h_peak_bits = nullptr, *d_peak_bits = nullptr; // [(max_sources + 31) / 32], bit k = entry k of the group
@@ -255,7 +262,7 @@ int group_of(int kind, const int32_t *fx, uint32_t n_fx) {
 	// reflection ring and one HRTF history per playback
 	int n_er = 0, n_hrtf = 0;
 	for (uint32_t j = 0; j < n_fx; j++) {
-		if (fx[j] != GAS_FX_HIGHSHELF && fx[j] != GAS_FX_EARLY_REFLECTIONS && fx[j] != GAS_FX_HRTF) {
+		if (fx[j] < GAS_FX_HIGHSHELF || fx[j] > GAS_FX_AMPLIFY) {
 			return -1;
 		}
 		n_er += fx[j] == GAS_FX_EARLY_REFLECTIONS;
@@ -275,6 +282,18 @@ inline bool uni_ok(const gas_ctx *c) {
 
 inline bool wants_peak(const gas_ctx *c, const SlotInfo &si) {
 	return si.draining || !(c->cfg.flags & GAS_FLAG_PEAKS_DRAINING_ONLY);
+}
+
+// [ENGINE] AudioEffectFilter / AudioEffectAmplify resource defaults
+gas_fx_settings fx_settings_defaults() {
+	gas_fx_settings d;
+	for (int j = 0; j < GAS_MAX_EFFECTS; j++) {
+		d.filter_cutoff_hz[j] = 2000.0f;
+		d.filter_resonance[j] = 0.5f;
+		d.filter_gain[j] = 1.0f;
+		d.amplify_volume_db[j] = 0.0f;
+	}
+	return d;
 }
 
 uint16_t chain_signature(const int32_t *fx, uint32_t n_fx) {
@@ -650,6 +669,8 @@ int run_groups(gas_ctx *c, const gas_audio_frame *d_src, const uint32_t *d_slots
 						gas_audio_frame *outb = c->d_chain[j & 1];
 						if (kind == GAS_FX_HIGHSHELF) {
 							e = gas_launch_biquad_mix(c->stream, GAS_MODE_FX_HIGHSHELF, in, c->st, F, (uint32_t)j, 1, c->cfg.mix_rate, parts, 0, c->partial_rows, reinterpret_cast<float *>(outb));
+						} else if (kind >= GAS_FX_LOWPASS && kind <= GAS_FX_AMPLIFY) { // the engine's other one-biquad filters and the amplifier: same kernel, settings by chain position
+							e = gas_launch_biquad_mix(c->stream, kind == GAS_FX_AMPLIFY ? GAS_MODE_FX_AMPLIFY : GAS_MODE_FX_FILTER, in, c->st, F, (uint32_t)j, 1, c->cfg.mix_rate, parts, 0, c->partial_rows, reinterpret_cast<float *>(outb), gas_bus_args(), kind);
 						} else if (kind == GAS_FX_EARLY_REFLECTIONS) {
 							e = gas_launch_er_only(c->stream, in, c->st, F, c->cfg.er_ring_frames, parts, 0, c->partial_rows, outb);
 						} else {
@@ -886,6 +907,36 @@ int flush_pending_params(gas_ctx *c) {
 	return GAS_OK;
 }
 
+// gas_fx_settings_publish's rows -> the slot-indexed device table.  Control-rate data: one 64-byte copy per changed slot
+// out of a pinned staging array, no kernel.
+int flush_fx_settings(gas_ctx *c) {
+	uint32_t m = 0;
+	{
+		std::lock_guard<std::mutex> lk(c->params_mu);
+		m = (uint32_t)c->fx_dirty_list.size();
+		if (m == 0) {
+			return GAS_OK;
+		}
+		if (!c->h_fx_upload) {
+			if (hipHostMalloc(&c->h_fx_upload, sizeof(gas_fx_settings) * c->cfg.max_sources, hipHostMallocDefault) != hipSuccess) {
+				return GAS_ERR_OUT_OF_MEMORY;
+			}
+		}
+		for (uint32_t i = 0; i < m; i++) {
+			const uint32_t s = c->fx_dirty_list[i];
+			c->h_fx_upload[i] = c->h_fxs[s];
+			c->h_upload_slots[i] = s; // (the parameter upload above has been waited for)
+			c->fx_dirty_flag[s] = 0;
+		}
+		c->fx_dirty_list.clear();
+	}
+	for (uint32_t i = 0; i < m; i++) {
+		GAS_HIP(c, hipMemcpyAsync(c->st.fxs + c->h_upload_slots[i], c->h_fx_upload + i, sizeof(gas_fx_settings), hipMemcpyHostToDevice, c->stream));
+	}
+	GAS_HIP(c, hipStreamSynchronize(c->stream));
+	return GAS_OK;
+}
+
 int flush_params(gas_ctx *c) {
 	uint32_t m = 0;
 	{
@@ -899,20 +950,29 @@ int flush_params(gas_ctx *c) {
 		}
 		c->dirty_list.clear();
 	}
-	if (m == 0) {
-		return GAS_OK;
+	if (m > 0) {
+		// the pinned upload buffers are reused next callback: the copies must have left the host first
+		GAS_HIP(c, hipMemcpyAsync(c->d_upload, c->h_upload, (size_t)m * sizeof(gas_params), hipMemcpyHostToDevice, c->stream));
+		GAS_HIP(c, hipMemcpyAsync(c->d_upload_slots, c->h_upload_slots, (size_t)m * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+		GAS_HIP(c, gas_launch_scatter_params(c->stream, c->st.params, c->d_upload, c->d_upload_slots, m));
+		GAS_HIP(c, hipStreamSynchronize(c->stream));
 	}
-	// the pinned upload buffers are reused next callback: the copies must have left the host first
-	GAS_HIP(c, hipMemcpyAsync(c->d_upload, c->h_upload, (size_t)m * sizeof(gas_params), hipMemcpyHostToDevice, c->stream));
-	GAS_HIP(c, hipMemcpyAsync(c->d_upload_slots, c->h_upload_slots, (size_t)m * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
-	GAS_HIP(c, gas_launch_scatter_params(c->stream, c->st.params, c->d_upload, c->d_upload_slots, m));
-	GAS_HIP(c, hipStreamSynchronize(c->stream));
-	return GAS_OK;
+	return flush_fx_settings(c);
 }
 
 void stream_rows_sync_back(gas_ctx *c);
 
+// Frees requested on other threads become the audio thread's pending frees (deferred like audio_spatializer.cpp:538-547).
+void adopt_frees(gas_ctx *c) {
+	std::lock_guard<std::mutex> lk(c->alloc_mu);
+	if (!c->free_inbox.empty()) {
+		c->pending_free.insert(c->pending_free.end(), c->free_inbox.begin(), c->free_inbox.end());
+		c->free_inbox.clear();
+	}
+}
+
 int apply_pending_frees(gas_ctx *c) {
+	adopt_frees(c);
 	if (c->pending_free.empty()) {
 		return GAS_OK;
 	}
@@ -924,6 +984,7 @@ int apply_pending_frees(gas_ctx *c) {
 		stream_rows_sync_back(c); // the compact mirror may still name these slots: fold it back before they are cleared
 		c->stream_groups_gen = UINT64_MAX;
 	}
+	std::lock_guard<std::mutex> alloc_lk(c->alloc_mu);
 	for (uint32_t s : c->pending_free) {
 		SlotInfo &si = c->slots[s];
 		si = SlotInfo{};
@@ -1134,6 +1195,8 @@ void gas_ctx_destroy(gas_ctx *c) {
 	(void)hipFree(c->d_tw);
 	(void)hipFree(c->d_upload);
 	(void)hipFree(c->d_upload_slots);
+	(void)hipFree(c->st.fxs);
+	(void)hipHostFree(c->h_fx_upload);
 	(void)hipFree(c->d_slots);
 	(void)hipFree(c->d_rows);
 	(void)hipFree(c->d_slots_rows);
@@ -1232,6 +1295,7 @@ int gas_ctx_create(const gas_config *cfg, gas_ctx **out_ctx) {
 		}
 		GAS_HIP(c, hipMalloc(&c->st.params, sizeof(gas_params) * N));
 		GAS_HIP(c, hipMemsetAsync(c->st.params, 0, sizeof(gas_params) * N, c->stream));
+		GAS_HIP(c, hipMalloc(&c->st.fxs, sizeof(gas_fx_settings) * N));
 		GAS_HIP(c, hipMalloc(&c->d_upload, sizeof(gas_params) * N));
 		GAS_HIP(c, hipMalloc(&c->d_upload_slots, sizeof(uint32_t) * N));
 		GAS_HIP(c, hipMalloc(&c->d_slots, sizeof(uint32_t) * N));
@@ -1283,10 +1347,19 @@ int gas_ctx_create(const gas_config *cfg, gas_ctx **out_ctx) {
 		return rc;
 	}
 	c->slots.resize(N);
-	c->h_routes.assign(N, gas_bus_route{ 0, GAS_BUS_NONE, {} });
+	c->h_routes.assign(N, gas_bus_route_default());
 	c->h_cursors.assign(N, gas_cursor{});
 	c->stamp.assign(N, 0);
 	c->dirty_flag.assign(N, 0);
+	c->h_fxs.assign(N, fx_settings_defaults());
+	c->fx_dirty_flag.assign(N, 0);
+	{ // every slot starts from the engine's resource defaults
+		const hipError_t e = hipMemcpy(c->st.fxs, c->h_fxs.data(), sizeof(gas_fx_settings) * N, hipMemcpyHostToDevice);
+		if (e != hipSuccess) {
+			gas_ctx_destroy(c);
+			return GAS_ERR_DEVICE;
+		}
+	}
 	c->free_list.reserve(N);
 	for (size_t s = N; s-- > 0;) {
 		c->free_list.push_back((uint32_t)s); // pop_back hands out 0, 1, 2, ...
@@ -1393,6 +1466,7 @@ int gas_source_alloc(gas_ctx *c, int kind, const int32_t *effects, uint32_t n_ef
 	if ((g == G_FX_ER || g == G_FX_ER_HRTF || (g == G_FX_GENERIC && chain_has(sig, GAS_FX_EARLY_REFLECTIONS))) && c->cfg.er_ring_frames == 0) {
 		return GAS_ERR_UNSUPPORTED_CHAIN;
 	}
+	std::lock_guard<std::mutex> alloc_lk(c->alloc_mu); // any thread (instantiate_playback_data runs on the physics thread, audio_spatializer.cpp:69)
 	if (c->free_list.empty()) {
 		return GAS_ERR_OUT_OF_SLOTS;
 	}
@@ -1409,6 +1483,17 @@ int gas_source_alloc(gas_ctx *c, int kind, const int32_t *effects, uint32_t n_ef
 	si.chain_sig = sig;
 	c->slots[s] = si;
 	*out_slot = s;
+	for (uint32_t j = 0; j < n_effects; j++) {
+		if (effects[j] >= GAS_FX_LOWPASS) { // a new playback's effect instances start from the resource defaults (audio_spatializer_effect.cpp:79-88)
+			std::lock_guard<std::mutex> lk(c->params_mu);
+			c->h_fxs[s] = fx_settings_defaults();
+			if (!c->fx_dirty_flag[s]) {
+				c->fx_dirty_flag[s] = 1;
+				c->fx_dirty_list.push_back(s);
+			}
+			break;
+		}
+	}
 	return GAS_OK;
 }
 
@@ -1416,12 +1501,13 @@ int gas_source_free(gas_ctx *c, uint32_t slot) {
 	if (!c) {
 		return GAS_ERR_INVALID_ARGUMENT;
 	}
+	std::lock_guard<std::mutex> alloc_lk(c->alloc_mu); // any thread (a RefCounted destructor runs wherever the last reference drops)
 	if (slot >= c->cfg.max_sources || !c->slots[slot].used || c->slots[slot].pending_free) {
 		return GAS_ERR_BAD_SLOT;
 	}
 	// deferred like audio_spatializer.cpp:538-547: the audio thread may still name it this callback
 	c->slots[slot].pending_free = 1;
-	c->pending_free.push_back(slot);
+	c->free_inbox.push_back(slot);
 	return GAS_OK;
 }
 
@@ -1473,6 +1559,27 @@ int gas_params_publish(gas_ctx *c, uint32_t slot, const gas_params *params) {
 		c->dirty_list.push_back(slot);
 	}
 	c->slots[slot].has_params = 1;
+	return GAS_OK;
+}
+
+int gas_fx_settings_publish(gas_ctx *c, const uint32_t *slots, const gas_fx_settings *settings, uint32_t n) {
+	if (!c || (n > 0 && (!slots || !settings))) {
+		return GAS_ERR_INVALID_ARGUMENT;
+	}
+	for (uint32_t i = 0; i < n; i++) {
+		if (slots[i] >= c->cfg.max_sources || !c->slots[slots[i]].used) {
+			return GAS_ERR_BAD_SLOT;
+		}
+	}
+	std::lock_guard<std::mutex> lk(c->params_mu);
+	for (uint32_t i = 0; i < n; i++) {
+		const uint32_t s = slots[i];
+		c->h_fxs[s] = settings[i];
+		if (!c->fx_dirty_flag[s]) {
+			c->fx_dirty_flag[s] = 1;
+			c->fx_dirty_list.push_back(s);
+		}
+	}
 	return GAS_OK;
 }
 
@@ -1704,6 +1811,49 @@ int gas_stream_destroy(gas_ctx *c, uint32_t stream) {
 	return GAS_OK;
 }
 
+int gas_stream_get_info(gas_ctx *c, uint32_t stream, uint64_t *out_frames, uint32_t *out_channels, int *out_format) {
+	if (!c) {
+		return GAS_ERR_INVALID_ARGUMENT;
+	}
+	if (stream >= c->streams.size() || !c->streams[stream].d_pcm) {
+		return GAS_ERR_BAD_SLOT;
+	}
+	if (out_frames) {
+		*out_frames = c->streams[stream].frames;
+	}
+	if (out_channels) {
+		*out_channels = c->streams[stream].channels;
+	}
+	if (out_format) {
+		*out_format = (int)c->streams[stream].format;
+	}
+	return GAS_OK;
+}
+
+int gas_stream_positions(gas_ctx *c, uint32_t n, uint64_t *out_frames) {
+	if (!c || (n > 0 && !out_frames)) {
+		return GAS_ERR_INVALID_ARGUMENT;
+	}
+	if (n != c->stream_slots_host.size()) {
+		return GAS_ERR_INVALID_ARGUMENT; // not the list of the last stream callback
+	}
+	// The compact row mirror holds the positions while the list is cached; a block boundary that applied deferred
+	// frees has folded it back into the per-slot cursors (stream_rows_sync_back) and emptied it.
+	const bool rows_live = c->stream_rows.size() == n;
+	for (uint32_t i = 0; i < n; i++) {
+		const gas_cursor &cur = c->h_cursors[c->stream_slots_host[i]];
+		if (!cur.pcm) {
+			out_frames[i] = 0;
+		} else if (rows_live) {
+			const gas_ctx::StreamRow &r = c->stream_rows[i];
+			out_frames[i] = r.resampled ? (r.fp_pos >> 16) : cur.frames - r.remaining;
+		} else {
+			out_frames[i] = cur.resampled ? (cur.fp_pos >> 16) : cur.pos;
+		}
+	}
+	return GAS_OK;
+}
+
 int gas_stream_set_resampled(gas_ctx *c, uint32_t stream, int on) {
 	if (!c) {
 		return GAS_ERR_INVALID_ARGUMENT;
@@ -1797,6 +1947,7 @@ int gas_process_block_streams(gas_ctx *c, const uint32_t *slots, uint32_t n, uin
 	}
 	// Steady state: same slot list as the previous stream callback, launch groups still cached, no parameter or
 	// binding change since -> skip validation and work on the compact row mirror.
+	adopt_frees(c);
 	bool same_list = c->pending_free.empty() /* a deferred free re-sorts the groups */ && c->stream_rows.size() == n && c->cached_n == n && c->stream_groups_gen == c->groups_gen && !c->stream_params_touched && c->stream_slots_host.size() == n && (n == 0 || std::memcmp(c->stream_slots_host.data(), slots, (size_t)n * sizeof(uint32_t)) == 0);
 	if (!same_list) {
 		stream_rows_sync_back(c);
@@ -2006,6 +2157,37 @@ int gas_hrtf_load(gas_ctx *c, const float *hrir, uint32_t dirs, uint32_t taps) {
 	return rc;
 }
 
+int gas_hrtf_load_positions(gas_ctx *c, const float *positions, const float *hrir, uint32_t m, uint32_t taps, uint32_t az_steps, uint32_t el_steps, int interpolation, float *out_hrir) {
+	if (!c || !positions || !hrir || m == 0 || taps == 0 || taps > GAS_HRTF_TAPS || az_steps == 0 || el_steps == 0 || (uint64_t)az_steps * el_steps > (1u << 20) || (interpolation != 0 && interpolation != 1)) {
+		return GAS_ERR_INVALID_ARGUMENT;
+	}
+	GAS_HIP(c, hipSetDevice(c->cfg.device));
+	const uint32_t dirs = az_steps * el_steps;
+	float *d_pos = nullptr, *d_in = nullptr, *d_grid = nullptr;
+	std::vector<float> grid((size_t)dirs * 2 * GAS_HRTF_TAPS);
+	int rc = [&]() -> int {
+		GAS_HIP(c, hipMalloc(&d_pos, (size_t)m * 2 * sizeof(float)));
+		GAS_HIP(c, hipMalloc(&d_in, (size_t)m * 2 * taps * sizeof(float)));
+		GAS_HIP(c, hipMalloc(&d_grid, grid.size() * sizeof(float)));
+		GAS_HIP(c, hipMemcpyAsync(d_pos, positions, (size_t)m * 2 * sizeof(float), hipMemcpyHostToDevice, c->stream));
+		GAS_HIP(c, hipMemcpyAsync(d_in, hrir, (size_t)m * 2 * taps * sizeof(float), hipMemcpyHostToDevice, c->stream));
+		GAS_HIP(c, gas_launch_hrtf_regrid(c->stream, d_pos, d_in, m, taps, az_steps, el_steps, interpolation, d_grid));
+		GAS_HIP(c, hipMemcpyAsync(grid.data(), d_grid, grid.size() * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+		GAS_HIP(c, hipStreamSynchronize(c->stream));
+		return GAS_OK;
+	}();
+	(void)hipFree(d_pos);
+	(void)hipFree(d_in);
+	(void)hipFree(d_grid);
+	if (rc != GAS_OK) {
+		return rc;
+	}
+	if (out_hrir) {
+		std::memcpy(out_hrir, grid.data(), grid.size() * sizeof(float));
+	}
+	return gas_hrtf_load(c, grid.data(), dirs, GAS_HRTF_TAPS);
+}
+
 int gas_process_block(gas_ctx *c, const gas_audio_frame *src, const uint32_t *slots, uint32_t n, uint32_t frames, gas_audio_frame *out, float *peaks, int mem) {
 	if (!c || !out || (mem != GAS_MEM_HOST && mem != GAS_MEM_DEVICE) || (n > 0 && !src) || n > c->cfg.max_sources) {
 		return GAS_ERR_INVALID_ARGUMENT;
@@ -2025,11 +2207,12 @@ int gas_process_block(gas_ctx *c, const gas_audio_frame *src, const uint32_t *sl
 	if (hipSetDevice(c->cfg.device) != hipSuccess) {
 		return fail(GAS_ERR_NO_DEVICE);
 	}
+	adopt_frees(c);
 	if (!c->deferred.empty()) { // GAS_FLAG_BATCHED_LAUNCH: do the waiting callbacks still see what they were recorded with?
 		bool host_dirty = false;
 		{
 			std::lock_guard<std::mutex> lk(c->params_mu);
-			host_dirty = !c->dirty_list.empty();
+			host_dirty = !c->dirty_list.empty() || !c->fx_dirty_list.empty();
 		}
 		const bool keep = mem == GAS_MEM_DEVICE && !slots && n == c->deferred_n && c->pending_free.empty() && c->groups_gen == c->deferred_groups_gen && !host_dirty;
 		if (!keep) {
@@ -2183,6 +2366,7 @@ int gas_process_block_buses(gas_ctx *c, const gas_audio_frame *src, const uint32
 	if (!c || !out || (mem != GAS_MEM_HOST && mem != GAS_MEM_DEVICE) || (n > 0 && !src) || n > c->cfg.max_sources || n_buses < 1 || n_buses > GAS_MAX_BUSES) {
 		return GAS_ERR_INVALID_ARGUMENT;
 	}
+	adopt_frees(c);
 	if (n > 0 && !slots && (c->cached_n != n || c->bus_form_cached == 0 || c->bus_form_groups_gen != c->groups_gen || !c->pending_free.empty())) {
 		return GAS_ERR_INVALID_ARGUMENT;
 	}

@@ -31,6 +31,7 @@ struct gas_dev_state {
 	gas_audio_frame *er_ring; // [max_sources][er_ring_frames]
 	uint32_t *er_pos; // [max_sources]
 	gas_params *params; // [max_sources]
+	gas_fx_settings *fxs; // [max_sources] settings of the engine-effect kinds (GAS_FX_LOWPASS .. GAS_FX_AMPLIFY), by chain position
 	uint8_t *was_further; // [max_sources] was_further_than_max_distance_last_frame (audio_spatializer_3d.h:118)
 };
 
@@ -76,12 +77,36 @@ enum gas_biquad_mode {
 	GAS_MODE_PROCESS_FRAMES = 1, // audio_spatializer_3d.cpp:491-552
 	GAS_MODE_FX_HIGHSHELF = 2, // [ENGINE] AudioEffectFilterInstance::process, 1 stage
 	GAS_MODE_COPY = 3, // empty effect chain, audio_spatializer_effect.cpp:41-46
+	GAS_MODE_FX_FILTER = 4, // [ENGINE] AudioEffectFilterInstance::process of the other AudioFilterSW modes, 1 stage; settings from gas_fx_settings
+	GAS_MODE_FX_AMPLIFY = 5, // [ENGINE] AudioEffectAmplifyInstance::process
 };
 
 struct gas_hrtf_table {
 	float4 *spec; // [dirs][4][64] = (HL.re, HL.im, HR.re, HR.im) of bin lane + 64 j < 256, pre-scaled by 1/512; Nyquist in DC.imag
 	uint32_t dirs;
 };
+
+static_assert(sizeof(gas_bus_route) == 8 + 32 + 4 * GAS_MAX_MORE_SENDS + 32 * GAS_MAX_MORE_SENDS, "gas_bus_route layout");
+
+__host__ __device__ inline gas_bus_route gas_bus_route_default() { // a slot that never got a route: dry bus 0, no send
+	gas_bus_route r{};
+	r.dry_bus = 0;
+	r.send_bus = GAS_BUS_NONE;
+	for (int k = 0; k < GAS_MAX_MORE_SENDS; k++) {
+		r.more_bus[k] = GAS_BUS_NONE;
+	}
+	return r;
+}
+
+// What a source sends to bus b for channel pair c and ear: dry 1 + the sends that name b, in field order.
+__host__ __device__ inline float gas_bus_weight(const gas_bus_route &r, uint32_t b, int c, int ear) {
+	float w = (r.dry_bus == b ? 1.0f : 0.0f) + (r.send_bus == b ? r.send[c][ear] : 0.0f);
+#pragma unroll
+	for (int k = 0; k < GAS_MAX_MORE_SENDS; k++) {
+		w += r.more_bus[k] == b ? r.more_send[k][c][ear] : 0.0f;
+	}
+	return w;
+}
 
 // Several output buses: per-slot routes and how many buses the launch writes.  n_buses <= 1 is the
 // single mix of gas_process_block (routes unused).  Partial layout with buses: plane (b * channel_count + c).
@@ -94,7 +119,7 @@ struct gas_bus_args {
 // Returns the number of partial mixes (per channel) it writes into `partials`
 // ([C][P][F*2] floats, row stride P_stride).
 uint32_t gas_biquad_partials(uint32_t n); // P for n sources
-hipError_t gas_launch_biquad_mix(hipStream_t stream, int mode, const gas_group_args &g, const gas_dev_state &st, uint32_t frames, uint32_t channel_begin, uint32_t channel_count, float mix_rate, float *partials, uint32_t p_offset, uint32_t p_stride, float *rows_out = nullptr /* non-null: per-source rows instead of the partial mix */, const gas_bus_args &buses = gas_bus_args());
+hipError_t gas_launch_biquad_mix(hipStream_t stream, int mode, const gas_group_args &g, const gas_dev_state &st, uint32_t frames, uint32_t channel_begin, uint32_t channel_count, float mix_rate, float *partials, uint32_t p_offset, uint32_t p_stride, float *rows_out = nullptr /* non-null: per-source rows instead of the partial mix */, const gas_bus_args &buses = gas_bus_args(), int fx_kind = 0 /* GAS_MODE_FX_FILTER: which GAS_FX_* filter */);
 
 // k_biquad_pipe.hip: the same arithmetic as an eight-wave software pipeline per 32 sources, for callbacks with fewer
 // workgroups than CUs (chosen inside gas_launch_biquad_mix)
@@ -140,6 +165,7 @@ hipError_t gas_launch_rows_accumulate(hipStream_t stream, const gas_group_args &
 hipError_t gas_launch_rows_accumulate_buses(hipStream_t stream, const gas_group_args &g, uint32_t frames, const gas_bus_route *routes, uint32_t n_buses, uint32_t bus_rows, float *partials, uint32_t p_offset); // bus b's partial rows: [b * bus_rows + p_offset + workgroup]
 
 hipError_t gas_launch_hrtf_table(hipStream_t stream, const float *d_hrir, uint32_t dirs, uint32_t taps, const float2 *twiddles, float4 *spec);
+hipError_t gas_launch_hrtf_regrid(hipStream_t stream, const float *d_positions, const float *d_hrir, uint32_t m, uint32_t taps, uint32_t az_steps, uint32_t el_steps, int interpolation, float *d_out /* [az_steps * el_steps][2][GAS_HRTF_TAPS] */);
 void gas_make_twiddles(float2 *host_tw /* [64][16] */);
 
 hipError_t gas_launch_mix_reduce(hipStream_t stream, const float *partials, uint32_t p_count, uint32_t p_stride, uint32_t channels, uint32_t frames, gas_audio_frame *out);

@@ -112,6 +112,10 @@ __device__ __forceinline__ void run_tiles(LaneState &L, float (&tile)[2][SRC_PER
 			}
 			if constexpr (MODE == GAS_MODE_COPY) {
 				y = x;
+			} else if constexpr (MODE == GAS_MODE_FX_AMPLIFY) {
+				// [ENGINE] AudioEffectAmplifyInstance::process: dst = src * vol; vol += vol_inc (co.b0 = vol, inc.b0 = vol_inc)
+				y = x * co.b0;
+				co.b0 += inc.b0;
 			} else {
 				// [ENGINE] process_one(_interp)
 				const float yf = x * co.b0 + hb1 * co.b1 + hb2 * co.b2 + ha1 * co.a1 + ha2 * co.a2;
@@ -129,7 +133,7 @@ __device__ __forceinline__ void run_tiles(LaneState &L, float (&tile)[2][SRC_PER
 					hb1 = filt ? x : hb1;
 					ha1 = filt ? yf : ha1;
 				}
-				if constexpr (MODE != GAS_MODE_FX_HIGHSHELF) {
+				if constexpr (MODE != GAS_MODE_FX_HIGHSHELF && MODE != GAS_MODE_FX_FILTER) {
 					co.b0 += inc.b0;
 					co.b1 += inc.b1;
 					co.b2 += inc.b2;
@@ -213,7 +217,7 @@ __device__ __forceinline__ void run_tiles(LaneState &L, float (&tile)[2][SRC_PER
 }
 
 template <int MODE>
-__global__ __launch_bounds__(64) void k_biquad_mix(gas_group_args g, gas_dev_state st, uint32_t F, uint32_t c0, float mix_rate, float *__restrict__ partials, uint32_t p_offset, uint32_t p_stride, float *__restrict__ rows_out, gas_bus_args buses) {
+__global__ __launch_bounds__(64) void k_biquad_mix(gas_group_args g, gas_dev_state st, uint32_t F, uint32_t c0, float mix_rate, float *__restrict__ partials, uint32_t p_offset, uint32_t p_stride, float *__restrict__ rows_out, gas_bus_args buses, int fx_kind) {
 	__shared__ float tile[2][SRC_PER_WG * ROW];
 	__shared__ float bus_w[GAS_MAX_BUSES * 64]; // [bus][source * 2 + ear]: what each source sends to each bus for this pair
 
@@ -258,7 +262,7 @@ __global__ __launch_bounds__(64) void k_biquad_mix(gas_group_args g, gas_dev_sta
 	float vs = 0, vf = 0;
 	bool filt = false;
 
-	if constexpr (MODE != GAS_MODE_COPY) {
+	if constexpr (MODE != GAS_MODE_COPY && MODE != GAS_MODE_FX_AMPLIFY) {
 		co.b0 = bq[BQ_B0 * bs + stream];
 		co.b1 = bq[BQ_B1 * bs + stream];
 		co.b2 = bq[BQ_B2 * bs + stream];
@@ -311,6 +315,22 @@ __global__ __launch_bounds__(64) void k_biquad_mix(gas_group_args g, gas_dev_sta
 		co = highshelf_coeffs(mix_rate, P->fx_shelf_cutoff_hz, P->fx_shelf_gain); // coefficients snap every call
 		filt = true;
 	}
+	if constexpr (MODE == GAS_MODE_FX_FILTER) { // chain position c: its settings, its state stream
+		const gas_fx_settings *S = st.fxs + slot;
+		co = filter_coeffs(fx_kind, mix_rate, S->filter_cutoff_hz[c], S->filter_resonance[c], S->filter_gain[c]);
+		filt = true;
+	}
+	float amp_db = 0.0f;
+	if constexpr (MODE == GAS_MODE_FX_AMPLIFY) {
+		// mix_volume_db lives in the PREV field of this position's state stream, B0 says whether a block has run: the
+		// instance starts at the resource's volume ([ENGINE] instantiate: mix_volume_db = volume_db), i.e. no ramp
+		amp_db = st.fxs[slot].amplify_volume_db[c];
+		const bool started = bq[BQ_B0 * bs + stream] != 0.0f;
+		const float from_db = started ? bq[BQ_PREV * bs + stream] : amp_db;
+		co.b0 = fx_db_to_linear(from_db); // vol
+		inc.b0 = (fx_db_to_linear(amp_db) - co.b0) / (float)(int)F; // vol_inc
+		filt = true;
+	}
 
 	const bool all_filt = __all(filt || !valid);
 	const bool f_pow2 = (F & (F - 1)) == 0;
@@ -318,14 +338,14 @@ __global__ __launch_bounds__(64) void k_biquad_mix(gas_group_args g, gas_dev_sta
 	const size_t bus_plane = (size_t)gridDim.y * p_stride * (size_t)F * 2; // floats between the partial planes of two buses
 	const uint32_t n_buses = buses.routes ? buses.n_buses : 0; // 0: the single mix of gas_process_block
 	if (n_buses > 0) {
-		gas_bus_route r{ 0, GAS_BUS_NONE, {} };
+		gas_bus_route r = gas_bus_route_default();
 		if (valid) {
 			r = buses.routes[slot];
 		}
 		for (uint32_t b = 0; b < n_buses; b++) {
 			float w = 0.0f;
 			if (valid) {
-				w = (r.dry_bus == b ? 1.0f : 0.0f) + (r.send_bus == b ? r.send[c][ear] : 0.0f);
+				w = gas_bus_weight(r, b, (int)c, ear);
 			}
 			bus_w[b * 64 + lane] = w;
 		}
@@ -353,7 +373,11 @@ __global__ __launch_bounds__(64) void k_biquad_mix(gas_group_args g, gas_dev_sta
 	const float peak = L.peak;
 
 	if (valid) {
-		if constexpr (MODE != GAS_MODE_COPY) {
+		if constexpr (MODE == GAS_MODE_FX_AMPLIFY) {
+			bq[BQ_B0 * bs + stream] = 1.0f;
+			bq[BQ_PREV * bs + stream] = amp_db; // mix_volume_db = volume_db
+		}
+		if constexpr (MODE != GAS_MODE_COPY && MODE != GAS_MODE_FX_AMPLIFY) {
 			if (filt) {
 				bq[BQ_B0 * bs + stream] = co.b0;
 				bq[BQ_B1 * bs + stream] = co.b1;
@@ -392,10 +416,10 @@ uint32_t gas_biquad_partials(uint32_t n) {
 bool gas_biquad_uses_pipe(int mode, uint32_t n, uint32_t channel_count, uint32_t frames, bool rows_out) {
 	const char *pipe_env = std::getenv("GAS_BIQUAD_PIPE");
 	const bool pipe_on = !(pipe_env && pipe_env[0] == '0');
-	return pipe_on && !rows_out && mode != GAS_MODE_COPY && gas_biquad_partials(n) * channel_count <= 256 && frames % 32 == 0;
+	return pipe_on && !rows_out && mode != GAS_MODE_COPY && mode != GAS_MODE_FX_FILTER && mode != GAS_MODE_FX_AMPLIFY && gas_biquad_partials(n) * channel_count <= 256 && frames % 32 == 0;
 }
 
-hipError_t gas_launch_biquad_mix(hipStream_t stream, int mode, const gas_group_args &g, const gas_dev_state &st, uint32_t frames, uint32_t channel_begin, uint32_t channel_count, float mix_rate, float *partials, uint32_t p_offset, uint32_t p_stride, float *rows_out, const gas_bus_args &buses) {
+hipError_t gas_launch_biquad_mix(hipStream_t stream, int mode, const gas_group_args &g, const gas_dev_state &st, uint32_t frames, uint32_t channel_begin, uint32_t channel_count, float mix_rate, float *partials, uint32_t p_offset, uint32_t p_stride, float *rows_out, const gas_bus_args &buses, int fx_kind) {
 	if (g.n == 0) {
 		return hipSuccess;
 	}
@@ -406,16 +430,22 @@ hipError_t gas_launch_biquad_mix(hipStream_t stream, int mode, const gas_group_a
 	}
 	switch (mode) {
 		case GAS_MODE_MIX_CHANNEL:
-			hipLaunchKernelGGL(k_biquad_mix<GAS_MODE_MIX_CHANNEL>, grid, block, 0, stream, g, st, frames, channel_begin, mix_rate, partials, p_offset, p_stride, rows_out, buses);
+			hipLaunchKernelGGL(k_biquad_mix<GAS_MODE_MIX_CHANNEL>, grid, block, 0, stream, g, st, frames, channel_begin, mix_rate, partials, p_offset, p_stride, rows_out, buses, fx_kind);
 			break;
 		case GAS_MODE_PROCESS_FRAMES:
-			hipLaunchKernelGGL(k_biquad_mix<GAS_MODE_PROCESS_FRAMES>, grid, block, 0, stream, g, st, frames, channel_begin, mix_rate, partials, p_offset, p_stride, rows_out, buses);
+			hipLaunchKernelGGL(k_biquad_mix<GAS_MODE_PROCESS_FRAMES>, grid, block, 0, stream, g, st, frames, channel_begin, mix_rate, partials, p_offset, p_stride, rows_out, buses, fx_kind);
 			break;
 		case GAS_MODE_FX_HIGHSHELF:
-			hipLaunchKernelGGL(k_biquad_mix<GAS_MODE_FX_HIGHSHELF>, grid, block, 0, stream, g, st, frames, channel_begin, mix_rate, partials, p_offset, p_stride, rows_out, buses);
+			hipLaunchKernelGGL(k_biquad_mix<GAS_MODE_FX_HIGHSHELF>, grid, block, 0, stream, g, st, frames, channel_begin, mix_rate, partials, p_offset, p_stride, rows_out, buses, fx_kind);
+			break;
+		case GAS_MODE_FX_FILTER:
+			hipLaunchKernelGGL(k_biquad_mix<GAS_MODE_FX_FILTER>, grid, block, 0, stream, g, st, frames, channel_begin, mix_rate, partials, p_offset, p_stride, rows_out, buses, fx_kind);
+			break;
+		case GAS_MODE_FX_AMPLIFY:
+			hipLaunchKernelGGL(k_biquad_mix<GAS_MODE_FX_AMPLIFY>, grid, block, 0, stream, g, st, frames, channel_begin, mix_rate, partials, p_offset, p_stride, rows_out, buses, fx_kind);
 			break;
 		case GAS_MODE_COPY:
-			hipLaunchKernelGGL(k_biquad_mix<GAS_MODE_COPY>, grid, block, 0, stream, g, st, frames, channel_begin, mix_rate, partials, p_offset, p_stride, rows_out, buses);
+			hipLaunchKernelGGL(k_biquad_mix<GAS_MODE_COPY>, grid, block, 0, stream, g, st, frames, channel_begin, mix_rate, partials, p_offset, p_stride, rows_out, buses, fx_kind);
 			break;
 		default:
 			return hipErrorInvalidValue;

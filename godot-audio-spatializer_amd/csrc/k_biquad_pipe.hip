@@ -143,12 +143,12 @@ __global__ __launch_bounds__(N_WAVES * 64) void k_biquad_pipe(gas_group_args g, 
 	const size_t bus_plane = (size_t)gridDim.y * p_stride * (size_t)F * 2; // floats between the partial planes of two buses
 	const uint32_t n_buses = buses.routes ? buses.n_buses : 0; // 0: the single mix of gas_process_block
 	if (n_buses > 0 && role == R_POST) { // only POST reads the weights (its own writes)
-		gas_bus_route r{ 0, GAS_BUS_NONE, {} };
+		gas_bus_route r = gas_bus_route_default();
 		if (valid) {
 			r = buses.routes[slot];
 		}
 		for (uint32_t b = 0; b < n_buses; b++) {
-			L.bus_w[b * 64 + lane] = valid ? (r.dry_bus == b ? 1.0f : 0.0f) + (r.send_bus == b ? r.send[c][ear] : 0.0f) : 0.0f;
+			L.bus_w[b * 64 + lane] = valid ? gas_bus_weight(r, b, (int)c, ear) : 0.0f;
 		}
 	}
 

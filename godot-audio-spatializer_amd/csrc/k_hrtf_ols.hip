@@ -769,8 +769,8 @@ __global__ __launch_bounds__(WAVES * 64) void k_rows_accumulate_buses(gas_group_
 		}
 #pragma unroll
 		for (int b = 0; b < NB; b++) {
-			const float wl = (r.dry_bus == (uint32_t)b ? 1.0f : 0.0f) + (r.send_bus == (uint32_t)b ? r.send[0][0] : 0.0f);
-			const float wr = (r.dry_bus == (uint32_t)b ? 1.0f : 0.0f) + (r.send_bus == (uint32_t)b ? r.send[0][1] : 0.0f);
+			const float wl = gas_bus_weight(r, (uint32_t)b, 0, 0);
+			const float wr = gas_bus_weight(r, (uint32_t)b, 0, 1);
 			if ((uint32_t)b < n_buses && (wl != 0.0f || wr != 0.0f)) { // wave-uniform
 #pragma unroll
 				for (int q = 0; q < FQ; q++) {

@@ -138,10 +138,10 @@ __global__ __launch_bounds__(UW * 64, UW > 8 ? 3 : GAS_HRTF_WAVES_PER_SIMD) void
 	if constexpr (BUS2) {
 		if (have) {
 			const gas_bus_route r = routes[lm.slot];
-			my_w0l = (r.dry_bus == 0u ? 1.0f : 0.0f) + (r.send_bus == 0u ? r.send[0][0] : 0.0f);
-			my_w0r = (r.dry_bus == 0u ? 1.0f : 0.0f) + (r.send_bus == 0u ? r.send[0][1] : 0.0f);
-			my_w1l = (r.dry_bus == 1u ? 1.0f : 0.0f) + (r.send_bus == 1u ? r.send[0][0] : 0.0f);
-			my_w1r = (r.dry_bus == 1u ? 1.0f : 0.0f) + (r.send_bus == 1u ? r.send[0][1] : 0.0f);
+			my_w0l = gas_bus_weight(r, 0u, 0, 0);
+			my_w0r = gas_bus_weight(r, 0u, 0, 1);
+			my_w1l = gas_bus_weight(r, 1u, 0, 0);
+			my_w1r = gas_bus_weight(r, 1u, 0, 1);
 		}
 #pragma unroll
 		for (int j = 0; j < 8; j++) {

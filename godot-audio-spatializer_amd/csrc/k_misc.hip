@@ -504,6 +504,113 @@ hipError_t gas_launch_scatter_params(hipStream_t stream, gas_params *table, cons
 	return hipGetLastError();
 }
 
+namespace {
+
+// Measured HRIR sets come as M irregular (azimuth, elevation) positions; the library indexes directions on an
+// azimuth x elevation grid (cell = elevation_index * az_steps + azimuth_index, the arithmetic of
+// k_calc_spatialization).  One workgroup per grid cell: every thread scans a strided share of the positions keeping its
+// three nearest (largest dot product with the cell's unit vector, ties to the smaller index), LDS-merges them into the
+// workgroup's three nearest, then writes the cell's HRIR pair: the nearest one (interpolation 0) or the blend of the
+// three weighted by 1 / angle (1).  NEW (AudioSpatializerHRTF, no reference counterpart): parity unpinned.
+struct Near3 {
+	float d[3];
+	uint32_t i[3];
+};
+
+__device__ __forceinline__ void near3_insert(Near3 &n, float d, uint32_t i) {
+	// keep (dot descending, index ascending)
+	if (d > n.d[2] || (d == n.d[2] && i < n.i[2])) {
+		n.d[2] = d;
+		n.i[2] = i;
+		if (n.d[2] > n.d[1] || (n.d[2] == n.d[1] && n.i[2] < n.i[1])) {
+			const float td = n.d[1];
+			const uint32_t ti = n.i[1];
+			n.d[1] = n.d[2];
+			n.i[1] = n.i[2];
+			n.d[2] = td;
+			n.i[2] = ti;
+			if (n.d[1] > n.d[0] || (n.d[1] == n.d[0] && n.i[1] < n.i[0])) {
+				const float ud = n.d[0];
+				const uint32_t ui = n.i[0];
+				n.d[0] = n.d[1];
+				n.i[0] = n.i[1];
+				n.d[1] = ud;
+				n.i[1] = ui;
+			}
+		}
+	}
+}
+
+constexpr int REGRID_THREADS = 256;
+
+__global__ __launch_bounds__(REGRID_THREADS) void k_hrtf_regrid(const float *__restrict__ positions /* [m][2] azimuth, elevation (radians) */, const float *__restrict__ hrir /* [m][2][taps] */, uint32_t m, uint32_t taps, uint32_t az_steps, uint32_t el_steps, int interpolation, float *__restrict__ out /* [az_steps * el_steps][2][GAS_HRTF_TAPS] */) {
+#pragma clang fp contract(off)
+	__shared__ float sd[REGRID_THREADS * 3];
+	__shared__ uint32_t si[REGRID_THREADS * 3];
+	__shared__ float best_w[3];
+	__shared__ uint32_t best_i[3];
+	const uint32_t cell = blockIdx.x, ai = cell % az_steps, ei = cell / az_steps;
+	const float az = (float)ai * (6.28318530717958647692f / (float)az_steps);
+	const float el = el_steps > 1 ? -1.57079632679489661923f + (float)ei * (3.14159265358979323846f / (float)(el_steps - 1)) : 0.0f;
+	// unit vector, azimuth from -Z towards +X, elevation from the XZ plane (audio_spatializer_hrtf.cpp fill_pod)
+	const float cx = cosf(el) * sinf(az), cy = sinf(el), cz = -cosf(el) * cosf(az);
+	Near3 n{ { -2.0f, -2.0f, -2.0f }, { 0xffffffffu, 0xffffffffu, 0xffffffffu } };
+	for (uint32_t k = threadIdx.x; k < m; k += REGRID_THREADS) {
+		const float paz = positions[2 * k], pel = positions[2 * k + 1];
+		const float px = cosf(pel) * sinf(paz), py = sinf(pel), pz = -cosf(pel) * cosf(paz);
+		near3_insert(n, (cx * px + cy * py) + cz * pz, k);
+	}
+	for (int j = 0; j < 3; j++) {
+		sd[threadIdx.x * 3 + j] = n.d[j];
+		si[threadIdx.x * 3 + j] = n.i[j];
+	}
+	__syncthreads();
+	if (threadIdx.x == 0) { // 768 candidates: a serial merge in the same (dot, index) order, deterministic
+		Near3 g{ { -2.0f, -2.0f, -2.0f }, { 0xffffffffu, 0xffffffffu, 0xffffffffu } };
+		for (int t = 0; t < REGRID_THREADS * 3; t++) {
+			if (si[t] != 0xffffffffu) {
+				near3_insert(g, sd[t], si[t]);
+			}
+		}
+		float w[3] = { 1.0f, 0.0f, 0.0f };
+		if (interpolation != 0 && g.i[1] != 0xffffffffu) {
+			float sum = 0.0f;
+			for (int j = 0; j < 3; j++) {
+				const float dot = fminf(1.0f, fmaxf(-1.0f, g.d[j]));
+				w[j] = g.i[j] != 0xffffffffu ? 1.0f / (acosf(dot) + 1e-4f) : 0.0f;
+				sum += w[j];
+			}
+			for (int j = 0; j < 3; j++) {
+				w[j] = w[j] / sum;
+			}
+		}
+		for (int j = 0; j < 3; j++) {
+			best_w[j] = w[j];
+			best_i[j] = g.i[j];
+		}
+	}
+	__syncthreads();
+	for (uint32_t t = threadIdx.x; t < 2 * GAS_HRTF_TAPS; t += REGRID_THREADS) {
+		const uint32_t ear = t / GAS_HRTF_TAPS, tap = t % GAS_HRTF_TAPS;
+		float v = 0.0f;
+		if (tap < taps) {
+			for (int j = 0; j < 3; j++) {
+				if (best_w[j] != 0.0f && best_i[j] != 0xffffffffu) {
+					v += best_w[j] * hrir[((size_t)best_i[j] * 2 + ear) * taps + tap];
+				}
+			}
+		}
+		out[((size_t)cell * 2 + ear) * GAS_HRTF_TAPS + tap] = v;
+	}
+}
+
+} // namespace
+
+hipError_t gas_launch_hrtf_regrid(hipStream_t stream, const float *d_positions, const float *d_hrir, uint32_t m, uint32_t taps, uint32_t az_steps, uint32_t el_steps, int interpolation, float *d_out) {
+	hipLaunchKernelGGL(k_hrtf_regrid, dim3(az_steps * el_steps), dim3(REGRID_THREADS), 0, stream, d_positions, d_hrir, m, taps, az_steps, el_steps, interpolation, d_out);
+	return hipGetLastError();
+}
+
 hipError_t gas_launch_zero_slot(hipStream_t stream, const gas_dev_state &st, uint32_t slot, uint32_t hist_len, uint32_t er_ring_frames) {
 	uint32_t work = hist_len > 8 ? hist_len : 8;
 	if (st.er_ring && er_ring_frames > work) {

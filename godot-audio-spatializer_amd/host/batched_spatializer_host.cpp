@@ -29,6 +29,12 @@ constexpr int TAIL = GAS_LOOKAHEAD_BUFFER_SIZE; // frames a playback runs ahead 
 // What control threads may look at once a playback has been handed to the audio thread.
 struct Shared {
 	std::atomic<bool> active{ true }; // cleared by stop_playback, by the silence gate, or by a start that failed
+	// set_playback_paused per playback (the reference pauses an instance's own proxies on AudioServer,
+	// audio_spatializer.cpp:115-122; with ONE proxy per bus for all players that would pause every player, so the pause
+	// lives here): a paused playback is neither sampled nor mixed, keeps its slot state and lookahead, is not gated and
+	// not reaped.  Read by the audio thread at the top of a callback.
+	std::atomic<bool> paused{ false };
+	std::atomic<uint64_t> position{ 0 }; // frames of the stream consumed so far ([ENGINE] AudioStreamPlayback::get_playback_position x mix rate); written by the audio thread
 };
 
 // One playback.  Built on a control thread, then owned by the audio thread until it is buried.
@@ -45,22 +51,27 @@ struct Playback {
 	int64_t array_frames = 0, array_pos = 0;
 	bool on_device = false;
 	uint32_t device_stream = 0;
-	uint64_t device_start = 0;
+	uint64_t device_start = 0; // first frame of this playback in its stream
+	uint64_t consumed = 0; // frames taken from the source so far
 	// audio-thread state
 	bool stream_live = true; // the source still has frames (has_frames, audio_spatializer.h:63)
 	bool have_params = false;
 	float pitch_scale = 1.0f;
+	gas_params params{}; // the row last published for this playback (what a process-effects hook may edit)
 	gas_audio_frame tail[TAIL]{}; // the 64 frames sampled ahead last callback
 
 	int pull(gas_audio_frame *dst, int frames) {
 		if (feed) {
-			return feed(feed_user, dst, pitch_scale, frames);
+			const int got = feed(feed_user, dst, pitch_scale, frames);
+			consumed += (uint64_t)(got > 0 ? got : 0);
+			return got;
 		}
 		const int64_t left = array_frames - array_pos;
 		const int got = (int)(left < frames ? (left < 0 ? 0 : left) : frames);
 		std::memcpy(dst, array + array_pos, sizeof(gas_audio_frame) * (size_t)got);
 		std::memset(dst + got, 0, sizeof(gas_audio_frame) * (size_t)(frames - got));
 		array_pos += got;
+		consumed += (uint64_t)got;
 		return got;
 	}
 };
@@ -97,9 +108,16 @@ struct gas_host {
 	std::mutex inbox_mu; // commands for the audio thread, and the nodes it has finished with
 	std::vector<Command> inbox;
 	std::vector<std::unique_ptr<Playback>> graveyard;
+	std::mutex hooks_mu; // the two callbacks below are set from a control thread
+	gas_host_release_fn release_fn = nullptr; // told about every playback the host has finished with (control thread)
+	void *release_user = nullptr;
+	gas_host_process_effects_fn effects_fn = nullptr; // _process_effects (audio_spatializer_effect.cpp:39,90-92): called on the audio thread
+	void *effects_user = nullptr;
 
 	// ---- audio thread only ----
-	std::vector<std::unique_ptr<Playback>> list; // newest first, like SafeList::insert at head
+	// Stored OLDEST first and walked from the back: the same newest-first order as SafeList::insert at head (SURVEY.md
+	// Appendix A item 7) gives, with an O(1) start instead of a head insertion into the vector.
+	std::vector<std::unique_ptr<Playback>> list;
 	std::unordered_map<uint32_t, Playback *> by_id;
 	std::vector<Command> batch; // the inbox of this callback
 	uint32_t served = 0xFu; // channel pairs handed out since the last mix; all set => the next request mixes (:78-80)
@@ -109,6 +127,7 @@ struct gas_host {
 	std::vector<Playback *> row_owner;
 	std::vector<float> peaks;
 	std::vector<uint8_t> live_out;
+	std::vector<uint64_t> positions;
 	std::vector<gas_audio_frame> mix; // [ctx_pairs][n]
 
 	// ---------------------------------------------------------------- control side
@@ -118,12 +137,28 @@ struct gas_host {
 		return it == registry.end() ? nullptr : it->second;
 	}
 
-	void empty_graveyard() { // node memory is released here, never on the audio thread
+	// Node memory is released here, never on the audio thread.  A registered release function hears about every
+	// playback first: from then on the host will not call its stream callback or touch its `user` again (the role of the
+	// Ref<AudioStreamPlayback> the reference's list node owns until its deferred delete, audio_spatializer.cpp:538-547).
+	int empty_graveyard() {
 		std::vector<std::unique_ptr<Playback>> dead;
 		{
 			std::lock_guard<std::mutex> lk(inbox_mu);
 			dead.swap(graveyard);
 		}
+		gas_host_release_fn fn;
+		void *fn_user;
+		{
+			std::lock_guard<std::mutex> lk(hooks_mu);
+			fn = release_fn;
+			fn_user = release_user;
+		}
+		if (fn) {
+			for (auto &pb : dead) {
+				fn(fn_user, pb->id, pb->feed_user);
+			}
+		}
+		return (int)dead.size();
 	}
 
 	int enqueue_start(std::unique_ptr<Playback> pb, uint32_t *out_id) {
@@ -182,7 +217,7 @@ struct gas_host {
 				// (the reference marks every channel pair "mixed" when the first playback starts, :78-80, so that the next
 				// request mixes; here a playback is only ever adopted inside the request that starts a new mix)
 				by_id[pb->id] = pb.get();
-				list.insert(list.begin(), std::move(pb)); // head insertion
+				list.push_back(std::move(pb)); // newest = last (walked from the back)
 			} else {
 				auto it = by_id.find(c.id);
 				if (it == by_id.end()) {
@@ -191,6 +226,7 @@ struct gas_host {
 				Playback *pb = it->second;
 				pb->pitch_scale = c.params.pitch_scale;
 				pb->have_params = true;
+				pb->params = c.params;
 				gas_params_publish(ctx, pb->slot, &c.params); // snapshotted by this callback's gas_process_block (:328)
 			}
 		}
@@ -249,10 +285,21 @@ struct gas_host {
 		if (!device_streams) {
 			window.resize((size_t)n + TAIL);
 		}
-		for (auto &up : list) {
-			Playback *pb = up.get();
-			if (!pb->shared->active.load() || !pb->have_params) { // :355-357; :330 parameters.is_null(): nothing is mixed
+		gas_host_process_effects_fn fx_hook;
+		void *fx_user;
+		{
+			std::lock_guard<std::mutex> lk(hooks_mu);
+			fx_hook = effects_fn;
+			fx_user = effects_user;
+		}
+		for (size_t k = list.size(); k-- > 0;) { // newest first
+			Playback *pb = list[k].get();
+			if (!pb->shared->active.load() || !pb->have_params || pb->shared->paused.load()) { // :355-357; :330 parameters.is_null(): nothing is mixed; paused: see Shared
 				continue;
+			}
+			if (fx_hook && fx_hook(fx_user, pb->id, &pb->params)) { // process_effects() runs first thing in process_frames (audio_spatializer_effect.cpp:39)
+				pb->pitch_scale = pb->params.pitch_scale;
+				gas_params_publish(ctx, pb->slot, &pb->params);
 			}
 			if (!device_streams) {
 				build_window(pb, window.data(), n);
@@ -268,8 +315,14 @@ struct gas_host {
 			live_out.assign((size_t)count + 1, 0);
 			rc = gas_process_block_streams(ctx, slots.data(), count, (uint32_t)n, mix.data(), peaks.data(), live_out.data(), GAS_MEM_HOST);
 			if (rc == GAS_OK) {
+				positions.resize((size_t)count + 1);
+				const bool have_pos = gas_stream_positions(ctx, count, positions.data()) == GAS_OK; // the library's mirror of the device cursors
 				for (uint32_t r = 0; r < count; r++) {
-					row_owner[r]->stream_live = live_out[r] != 0; // audio_spatializer.cpp:398
+					Playback *pb = row_owner[r];
+					if (have_pos && positions[r] >= pb->device_start) {
+						pb->consumed = positions[r] - pb->device_start;
+					}
+					pb->stream_live = live_out[r] != 0; // audio_spatializer.cpp:398
 				}
 			}
 		} else {
@@ -278,23 +331,30 @@ struct gas_host {
 		if (rc != GAS_OK) {
 			return rc; // the library zero-filled the mix
 		}
+		for (uint32_t r = 0; r < count; r++) {
+			row_owner[r]->shared->position.store(row_owner[r]->consumed, std::memory_order_relaxed);
+		}
 		gate(count);
 		return GAS_OK;
 	}
 
 	// audio_spatializer.cpp:473-492: inactive playbacks leave the list; their slot is freed at the next block boundary
-	void reap() {
-		for (size_t i = 0; i < list.size();) {
+	void reap() { // one stable compaction pass, whatever the number of playbacks that ended
+		size_t keep = 0;
+		for (size_t i = 0; i < list.size(); i++) {
 			if (list[i]->shared->active.load()) {
-				i++;
+				if (keep != i) {
+					list[keep] = std::move(list[i]);
+				}
+				keep++;
 				continue;
 			}
 			std::unique_ptr<Playback> pb = std::move(list[i]);
-			list.erase(list.begin() + (long)i);
 			by_id.erase(pb->id);
 			gas_source_free(ctx, pb->slot);
 			bury(std::move(pb));
 		}
+		list.resize(keep);
 	}
 
 	// audio_spatializer.cpp:494-508 as a bit set: a pair that was already handed out since the last mix starts a new
@@ -353,6 +413,19 @@ void gas_host_destroy(gas_host *h) { // no thread may be inside the host any mor
 	for (auto &pb : h->list) {
 		gas_source_free(h->ctx, pb->slot);
 	}
+	{ // everything still on the list or in the inbox is finished with as well
+		std::lock_guard<std::mutex> lk(h->inbox_mu);
+		for (auto &pb : h->list) {
+			h->graveyard.push_back(std::move(pb));
+		}
+		for (Command &c : h->inbox) {
+			if (c.playback) {
+				h->graveyard.push_back(std::move(c.playback));
+			}
+		}
+	}
+	h->list.clear();
+	h->empty_graveyard();
 	delete h;
 }
 
@@ -439,6 +512,57 @@ void gas_host_set_playback_disable_threshold_db(gas_host *h, float db) {
 int gas_host_is_playback_active(gas_host *h, uint32_t id) {
 	std::shared_ptr<Shared> s = h ? h->lookup(id) : nullptr;
 	return s && s->active.load() ? 1 : 0;
+}
+
+int gas_host_set_playback_paused(gas_host *h, uint32_t id, int paused) {
+	std::shared_ptr<Shared> s = h ? h->lookup(id) : nullptr;
+	if (!s) {
+		return GAS_ERR_BAD_SLOT;
+	}
+	s->paused.store(paused != 0); // seen by the audio thread at the top of the next callback
+	return GAS_OK;
+}
+
+int gas_host_is_playback_paused(gas_host *h, uint32_t id) {
+	std::shared_ptr<Shared> s = h ? h->lookup(id) : nullptr;
+	return s && s->active.load() && s->paused.load() ? 1 : 0;
+}
+
+int gas_host_get_playback_position(gas_host *h, uint32_t id, uint64_t *out_frames) {
+	if (!out_frames) {
+		return GAS_ERR_INVALID_ARGUMENT;
+	}
+	std::shared_ptr<Shared> s = h ? h->lookup(id) : nullptr;
+	if (!s) {
+		*out_frames = 0; // audio_spatializer.cpp:152-155: an unknown playback reports 0
+		return GAS_ERR_BAD_SLOT;
+	}
+	*out_frames = s->position.load(std::memory_order_relaxed);
+	return GAS_OK;
+}
+
+int gas_host_set_release_fn(gas_host *h, gas_host_release_fn fn, void *user) {
+	if (!h) {
+		return GAS_ERR_INVALID_ARGUMENT;
+	}
+	std::lock_guard<std::mutex> lk(h->hooks_mu);
+	h->release_fn = fn;
+	h->release_user = user;
+	return GAS_OK;
+}
+
+int gas_host_collect_released(gas_host *h) {
+	return h ? h->empty_graveyard() : GAS_ERR_INVALID_ARGUMENT;
+}
+
+int gas_host_set_process_effects_fn(gas_host *h, gas_host_process_effects_fn fn, void *user) {
+	if (!h) {
+		return GAS_ERR_INVALID_ARGUMENT;
+	}
+	std::lock_guard<std::mutex> lk(h->hooks_mu);
+	h->effects_fn = fn; // the audio thread picks the pair up at the top of its next callback
+	h->effects_user = user;
+	return GAS_OK;
 }
 
 int gas_host_playback_count(gas_host *h) {

@@ -22,7 +22,31 @@ struct HostKeyHasher {
 	static uint32_t hash(const HostKey &k) { return hash_murmur3_one_32(k.chain, hash_murmur3_one_32((uint32_t)k.kind, k.bus.hash())); }
 };
 HashMap<HostKey, gas_host *, HostKeyHasher> hosts;
+
+// The engine playbacks the hosts may still call mix() on, keyed by the pointer handed to gas_host_start_playback as
+// `user`.  Control threads only (retain: before the start; released: inside gas_host_start_playback*,
+// gas_host_collect_released or gas_host_destroy) -- never the audio thread.
+Mutex retained_mutex;
+HashMap<AudioStreamPlayback *, Ref<AudioStreamPlayback>> retained;
+void released(void *, uint32_t, void *p_user) {
+	Ref<AudioStreamPlayback> last; // destroyed after the lock is gone: a playback's destructor may be arbitrary engine code
+	MutexLock lock(retained_mutex);
+	AudioStreamPlayback *key = static_cast<AudioStreamPlayback *>(p_user);
+	if (Ref<AudioStreamPlayback> *r = retained.getptr(key)) {
+		last = *r;
+		retained.erase(key);
+	}
+}
 } // namespace
+
+void GasModule::retain(const Ref<AudioStreamPlayback> &p_playback) {
+	MutexLock lock(retained_mutex);
+	retained.insert(p_playback.ptr(), p_playback);
+}
+
+void GasModule::unretain(AudioStreamPlayback *p_playback) {
+	released(nullptr, 0, p_playback);
+}
 
 gas_ctx *GasModule::ctx() {
 	MutexLock lock(gas_mutex);
@@ -63,6 +87,7 @@ gas_host *GasModule::host_for(const StringName &p_bus, int p_kind, const int32_t
 	gas_host *h = nullptr;
 	const int rc = gas_host_create(c, p_kind, p_effects, p_n_effects, &h);
 	ERR_FAIL_COND_V_MSG(rc != GAS_OK, nullptr, gas_strerror(rc));
+	gas_host_set_release_fn(h, released, nullptr);
 	hosts.insert(key, h);
 	return h;
 }

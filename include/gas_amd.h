@@ -11,12 +11,15 @@
  * (SURVEY.md section 5).  All file:line citations are in the reference tree.
  *
  * Threading contract (same split as audio_spatializer.h:135-138):
- *   - gas_params_publish*  : physics thread, may run concurrently with the audio thread.
- *   - gas_process_block, gas_process_frames_1, gas_mix_channel_1 : audio thread only,
- *     one caller at a time, never re-entrant per context.
+ *   - gas_params_publish*, gas_bus_routes_publish : physics thread, may run concurrently with the audio thread.
+ *   - gas_source_alloc, gas_source_free : any thread, concurrently with the audio thread (instantiate_playback_data runs
+ *     on the physics thread, audio_spatializer.cpp:69; playback data is released wherever its last reference drops).
+ *     The slot allocator takes a lock; a free takes effect at the audio thread's next block boundary; a slot is
+ *     handed to the audio thread by the caller (the first callback whose list names it), never before alloc returned.
+ *   - gas_process_block*, gas_process_frames_1, gas_mix_channel_1, gas_source_set_draining, gas_source_bind_stream,
+ *     gas_stream_positions : audio thread only, one caller at a time, never re-entrant per context.
  *   - everything else      : one thread at a time and not concurrently with the audio-thread entries -- the main
- *     thread while audio is stopped, or the audio thread itself between callbacks (what gas_amd_host.h's host layer
- *     does for slot alloc / free / draining / stream binding, so that start/stop from other threads never race).
+ *     thread while audio is stopped, or the audio thread itself between callbacks.
  */
 #ifndef GAS_AMD_H
 #define GAS_AMD_H
@@ -73,6 +76,15 @@ typedef enum gas_effect_kind {
 	GAS_FX_HIGHSHELF = 1, /* [ENGINE] AudioEffectHighShelfFilter, FILTER_6DB (gd_spatializer.gd:14-19) */
 	GAS_FX_EARLY_REFLECTIONS = 2, /* NEW: 8 stereo delay taps from a per-source ring */
 	GAS_FX_HRTF = 3, /* NEW: mono downmix -> gain ramp -> 256-tap HRIR pair, overlap-save FFT */
+	/* audio_spatializer_effect.cpp:79-88 instantiates ANY AudioEffect; these are the engine's other one-biquad filters
+	 * ([ENGINE] AudioEffectFilter subclasses at FILTER_6DB = one AudioFilterSW stage per ear, coefficients snapped per
+	 * block) and AudioEffectAmplify.  Their settings are per playback and chain position: gas_fx_settings. */
+	GAS_FX_LOWPASS = 4, /* [ENGINE] AudioEffectLowPassFilter */
+	GAS_FX_HIGHPASS = 5, /* [ENGINE] AudioEffectHighPassFilter */
+	GAS_FX_BANDPASS = 6, /* [ENGINE] AudioEffectBandPassFilter */
+	GAS_FX_NOTCH = 7, /* [ENGINE] AudioEffectNotchFilter */
+	GAS_FX_LOWSHELF = 8, /* [ENGINE] AudioEffectLowShelfFilter */
+	GAS_FX_AMPLIFY = 9, /* [ENGINE] AudioEffectAmplify: volume ramp previous -> current volume_db across the block */
 } gas_effect_kind;
 
 typedef enum gas_mem {
@@ -167,6 +179,17 @@ typedef struct gas_params {
 	uint32_t er_delay[GAS_ER_TAPS]; /* NEW: 1 .. er_ring_frames - frames */
 } gas_params;
 
+/* Settings of the GAS_FX_LOWPASS .. GAS_FX_AMPLIFY effects of one playback, by chain position (what a script sets on
+ * the AudioEffect resources from _process_effects, gd_spatializer_instance.gd:125-127).  Position j is read only when
+ * effect j of the playback's chain is one of those kinds.  A slot that never got settings has the engine's resource
+ * defaults: cutoff 2000 Hz, resonance 0.5, gain 1, volume 0 dB. */
+typedef struct gas_fx_settings {
+	float filter_cutoff_hz[GAS_MAX_EFFECTS]; /* [ENGINE] AudioEffectFilter::cutoff */
+	float filter_resonance[GAS_MAX_EFFECTS]; /* [ENGINE] AudioEffectFilter::resonance */
+	float filter_gain[GAS_MAX_EFFECTS]; /* [ENGINE] AudioEffectFilter::gain (linear; shelf kinds) */
+	float amplify_volume_db[GAS_MAX_EFFECTS]; /* [ENGINE] AudioEffectAmplify::volume_db */
+} gas_fx_settings;
+
 /* Per-kernel device timing collected with HIP events on the context stream. */
 typedef struct gas_profile {
 	uint64_t launches; /* timed launches of the dominant kernel since the last reset */
@@ -201,8 +224,8 @@ const char *gas_last_device_error(gas_ctx *ctx);
  * deferred delete (audio_spatializer.cpp:538-547) ------------------------ */
 /* GAS_KIND_EFFECT chains (audio_spatializer_effect.cpp:33-77): up to GAS_MAX_EFFECTS of GAS_FX_*, in processing
  * order, with at most one EARLY_REFLECTIONS (needs cfg.er_ring_frames) and one HRTF per playback.  [], [HIGHSHELF],
- * [ER], [HRTF] and [ER, HRTF] run as one fused kernel; any other order runs one launch per effect through ping-pong
- * row buffers, as the reference's loop does.  Everything else: GAS_ERR_UNSUPPORTED_CHAIN. */
+ * [ER], [HRTF] and [ER, HRTF] run as one fused kernel; any other order or kind runs one launch per effect through
+ * ping-pong row buffers, as the reference's loop does.  Everything else: GAS_ERR_UNSUPPORTED_CHAIN. */
 int gas_source_alloc(gas_ctx *ctx, int kind, const int32_t *effects, uint32_t n_effects, uint32_t *out_slot);
 int gas_source_free(gas_ctx *ctx, uint32_t slot); /* takes effect at the next block boundary */
 int gas_source_reset(gas_ctx *ctx, uint32_t slot); /* zero the slot's DSP state (a restarted playback) */
@@ -218,8 +241,24 @@ int gas_params_publish(gas_ctx *ctx, uint32_t slot, const gas_params *params);
  * is enqueued, so the buffer must stay valid and unmodified on other streams until then. */
 int gas_params_publish_batch(gas_ctx *ctx, const uint32_t *slots, const gas_params *params, uint32_t n, int params_mem);
 
+/* Settings of the engine-effect kinds, host arrays; latest wins, snapshotted with the parameters at the start of the
+ * next gas_process_block.  Physics thread, like gas_params_publish. */
+int gas_fx_settings_publish(gas_ctx *ctx, const uint32_t *slots, const gas_fx_settings *settings, uint32_t n);
+
 /* ---- NEW AudioSpatializerHRTF resource: hrir is [dirs][2 ears][taps] f32, taps <= 256 */
 int gas_hrtf_load(gas_ctx *ctx, const float *hrir, uint32_t dirs, uint32_t taps);
+/* The same resource from a MEASURED set (what a SOFA file holds: M source positions x 2 receivers x N samples; parsing
+ * netCDF / HDF5 is the caller's business, the loader takes the arrays).  positions is [m][2] = (azimuth, elevation) in
+ * radians, azimuth from straight ahead (-Z) towards the right (+X), elevation up from the horizontal plane -- SOFA's
+ * spherical convention is azimuth counter-clockwise in degrees: azimuth = -radians(sofa_azimuth).  hrir is
+ * [m][2 ears][taps], taps <= 256 (shorter sets are zero-padded).  The set is regridded ON THE DEVICE onto the
+ * az_steps x el_steps grid the library indexes directions with (hrtf_dir = elevation_index * az_steps + azimuth_index;
+ * azimuth_index = round(az / 2pi * az_steps) mod az_steps, elevation_index = round((el + pi/2) / pi * (el_steps - 1)):
+ * the cells gas_calc_spatialization writes): interpolation 0 takes the measurement nearest on the sphere, 1 blends the
+ * three nearest with weights 1 / (angle + 1e-4) -- a time-domain blend, adequate for dense sets only.  out_hrir, when
+ * non-NULL, receives the gridded set [az_steps * el_steps][2][256] (what gas_hrtf_load was then called with).  NEW, no
+ * reference counterpart: parity unpinned.  Main thread, like gas_hrtf_load. */
+int gas_hrtf_load_positions(gas_ctx *ctx, const float *positions, const float *hrir, uint32_t m, uint32_t taps, uint32_t az_steps, uint32_t el_steps, int interpolation, float *out_hrir);
 
 /* ---- the hot path: body of _mix_from_playback_list (audio_spatializer.cpp:353-470)
  * for n sources at once.  src is [n][frames] AudioFrames, row i already holds the
@@ -244,11 +283,18 @@ int gas_process_block(gas_ctx *ctx, const gas_audio_frame *src, const uint32_t *
  *     out[b][c][i] = sum over sources with dry_bus == b of y[c][i]  +  sum over sources with send_bus == b of y[c][i] * send[c]
  * (y = the source's mix_channel output for pair c).  GAS_KIND_3D_MIX sources only. */
 #define GAS_MAX_BUSES GAS_MAX_BUSES_PER_PLAYBACK
+#define GAS_MAX_MORE_SENDS (GAS_MAX_BUSES_PER_PLAYBACK - 2)
 #define GAS_BUS_NONE 0xffffffffu
+/* A playback reaches up to GAS_MAX_BUSES_PER_PLAYBACK buses (audio_spatializer.cpp:283-287 walks every key of
+ * bus_volumes up to that many): the dry bus and up to five sends.  AudioSpatializer3D uses the dry bus and one send
+ * (audio_spatializer_3d.cpp:437-461): the first two fields; a script subclass with more buses fills more_*.  A bus
+ * named more than once receives the sum of its weights. */
 typedef struct gas_bus_route {
 	uint32_t dry_bus; /* index < n_buses of the call, or GAS_BUS_NONE */
-	uint32_t send_bus; /* index < n_buses, or GAS_BUS_NONE: no send */
+	uint32_t send_bus; /* first send: index < n_buses, or GAS_BUS_NONE */
 	float send[GAS_MAX_CHANNELS_PER_BUS][2]; /* bus_volume / mix_volume per channel pair and ear (gas_host_bus_map arithmetic) */
+	uint32_t more_bus[GAS_MAX_MORE_SENDS]; /* further sends; GAS_BUS_NONE = unused */
+	float more_send[GAS_MAX_MORE_SENDS][GAS_MAX_CHANNELS_PER_BUS][2];
 } gas_bus_route;
 /* Host arrays; latest wins, snapshotted at the next gas_process_block_buses.  A slot that never got a route is
  * {dry_bus 0, no send}.  Physics thread, like gas_params_publish. */
@@ -354,6 +400,8 @@ int gas_stream_create(gas_ctx *ctx, const void *pcm, int format, uint32_t channe
  *                  published from the host (gas_params_publish*); 0 <= pitch_scale < 32768. */
 int gas_stream_set_resampled(gas_ctx *ctx, uint32_t stream, int on);
 int gas_stream_destroy(gas_ctx *ctx, uint32_t stream);
+/* Length, channel count and sample format of a stream (any of the outputs may be NULL). */
+int gas_stream_get_info(gas_ctx *ctx, uint32_t stream, uint64_t *out_frames, uint32_t *out_channels, int *out_format);
 /* start_playback_stream (audio_spatializer.cpp:55-63): the slot's playback starts at start_frame of the stream
  * with a zeroed lookahead and has_frames set. */
 int gas_source_bind_stream(gas_ctx *ctx, uint32_t slot, uint32_t stream, uint64_t start_frame);
@@ -362,6 +410,11 @@ int gas_source_bind_stream(gas_ctx *ctx, uint32_t slot, uint32_t stream, uint64_
  * receives each playback's has_frames flag after this callback (audio_spatializer.cpp:398); slots whose
  * stream ended are marked draining automatically.  out / peaks are host or device pointers per `mem`. */
 int gas_process_block_streams(gas_ctx *ctx, const uint32_t *slots, uint32_t n, uint32_t frames, gas_audio_frame *out, float *peaks, uint8_t *has_frames, int mem);
+/* Where the playbacks of the LAST gas_process_block_streams list stand in their streams after it, in its row order:
+ * out_frames[i] = index of the next stream frame playback i will take ([ENGINE] get_playback_position x mix rate, plus
+ * the playback's start frame).  From the host-side mirror of the cursor arithmetic: nothing is read back from the
+ * device.  n must be that callback's n.  Audio thread. */
+int gas_stream_positions(gas_ctx *ctx, uint32_t n, uint64_t *out_frames);
 
 /* ---- measurement ------------------------------------------------------- */
 /* on = 0 off, 1 = bracket the dominant launch of every callback with HIP events, N > 1 = of every Nth callback. */

@@ -11,7 +11,9 @@
  *
  * Threading contract (the reference's split, audio_spatializer.h:135-138, with its SafeList / SafeFlag / Mutex roles):
  *   - control entries -- gas_host_start_playback*, gas_host_stop_playback, gas_host_set_spatializer_parameters,
- *     gas_host_set_playback_disable_threshold_db, gas_host_is_playback_active, gas_host_playback_count -- may be
+ *     gas_host_set_playback_disable_threshold_db, gas_host_is_playback_active, gas_host_set_playback_paused,
+ *     gas_host_is_playback_paused, gas_host_get_playback_position, gas_host_playback_count, gas_host_set_release_fn,
+ *     gas_host_collect_released, gas_host_set_process_effects_fn -- may be
  *     called from any number of threads (main, physics) at any time, concurrently with the audio thread.  They only
  *     queue commands / flip per-playback atomics; a start or a parameter set takes effect at the top of the next
  *     callback, in the order issued (one parameter snapshot per callback, audio_spatializer.cpp:328).
@@ -55,7 +57,40 @@ int gas_host_stop_playback(gas_host *host, uint32_t id);
 int gas_host_set_spatializer_parameters(gas_host *host, uint32_t id, const gas_params *params);
 void gas_host_set_playback_disable_threshold_db(gas_host *host, float db); /* audio_spatializer.h:87 */
 int gas_host_is_playback_active(gas_host *host, uint32_t id);
+/* set_playback_paused / is_playback_paused (audio_spatializer.cpp:115-122, :161-170), PER PLAYBACK: the reference
+ * pauses the instance's own proxy playbacks on AudioServer, which a host with one shared proxy per bus cannot do
+ * without pausing every player.  A paused playback is neither sampled nor mixed from the next callback on; its slot
+ * state, its 64-frame lookahead and its stream position are kept; it is not gated and not reaped; un-pausing resumes
+ * it where it stopped (also in the middle of its ring-out).  No fade: AudioServer's pause fade works on a proxy's
+ * output ([ENGINE]), not inside the module.  A player with polyphony pauses each of its playback ids. */
+int gas_host_set_playback_paused(gas_host *host, uint32_t id, int paused);
+int gas_host_is_playback_paused(gas_host *host, uint32_t id);
+/* get_playback_position (audio_spatializer.cpp:144-157) in frames of the stream consumed so far (what
+ * [ENGINE] AudioStreamPlayback::get_playback_position reports, times the mix rate; it runs 64 frames ahead of what is
+ * audible, like the reference's): counted by the audio thread for callback and array playbacks, mirrored from the
+ * device cursor arithmetic for device-stream playbacks (nothing is read back).  Unknown id: 0 and GAS_ERR_BAD_SLOT. */
+int gas_host_get_playback_position(gas_host *host, uint32_t id, uint64_t *out_frames);
 int gas_host_playback_count(gas_host *host); /* nodes still on the list */
+
+/* Who owns `user` of gas_host_start_playback: the reference's list node holds a Ref<AudioStreamPlayback> until its
+ * deferred delete (audio_spatializer.cpp:538-547), so a caller may drop its own reference right after stop_playback.
+ * Here the caller keeps `user` alive until the host says it is finished with it: `fn(fn_user, id, user)` is called once
+ * per playback (user is NULL for array / device-stream playbacks), after which the host never calls its stream callback
+ * again.  It runs on a CONTROL thread -- inside gas_host_start_playback*, gas_host_collect_released or gas_host_destroy,
+ * whichever comes first after the audio thread reaped the playback -- never on the audio thread. */
+typedef void (*gas_host_release_fn)(void *fn_user, uint32_t id, void *user);
+int gas_host_set_release_fn(gas_host *host, gas_host_release_fn fn, void *fn_user);
+/* Release what the audio thread has finished with (call it from the physics tick); returns the number of playbacks. */
+int gas_host_collect_released(gas_host *host);
+
+/* _process_effects(params, playback_data) (audio_spatializer_effect.cpp:39,90-92; the example's
+ * gd_spatializer_instance.gd:125-127 sets its high-shelf's gain from the parameters there): called on the AUDIO thread,
+ * once per audible playback per callback, before the launch, with the parameter row last set for the playback.  The
+ * effects' settings live in that row (highshelf_*, er_*, hrtf_* of gas_params), so "edit the effect" = edit the row;
+ * a non-zero return publishes the edited row for this callback (and keeps it until the next
+ * gas_host_set_spatializer_parameters).  NULL removes the hook. */
+typedef int (*gas_host_process_effects_fn)(void *fn_user, uint32_t id, gas_params *params);
+int gas_host_set_process_effects_fn(gas_host *host, gas_host_process_effects_fn fn, void *fn_user);
 
 /* get_mixed_frames (audio_spatializer.cpp:510-527): audio thread; returns GAS_OK, GAS_ERR_BAD_CHANNEL
  * ("Unexpected channel") or GAS_ERR_FRAME_COUNT ("Unexpected frame count"). */

@@ -23,6 +23,7 @@ MAX_EFFECTS = 4
 FX_HIGHSHELF = 1
 FX_EARLY_REFLECTIONS = 2
 FX_HRTF = 3
+FX_LOWPASS, FX_HIGHPASS, FX_BANDPASS, FX_NOTCH, FX_LOWSHELF, FX_AMPLIFY = 4, 5, 6, 7, 8, 9
 
 KIND_3D_MIX = 0
 KIND_3D_PROCESS = 1
@@ -93,6 +94,12 @@ class FxState(C.Structure):
         ("hist", C.c_float * (HRTF_TAPS - 1)),
         ("prev_gain", C.c_float),
         ("prev_dir_plus1", C.c_int32),
+        ("cutoff_hz", C.c_float),
+        ("resonance", C.c_float),
+        ("gain", C.c_float),
+        ("volume_db", C.c_float),
+        ("amp_mix_volume_db", C.c_float),
+        ("amp_started", C.c_int32),
     ]
 
 
@@ -116,7 +123,7 @@ class Playback(C.Structure):
         ("pdfx", PDataEffect),
         ("last_peak", C.c_float * 2),
         ("resampled", C.c_int32),
-        ("pad_", C.c_int32),
+        ("paused", C.c_int32),
         ("mix_offset", C.c_uint64),
     ]
 
@@ -262,11 +269,19 @@ class BatchOracle:
             pd.n_effects = len(chain)
             for j, k in enumerate(chain):
                 pd.kinds[j] = k
+                pd.fx[j].cutoff_hz, pd.fx[j].resonance, pd.fx[j].gain, pd.fx[j].volume_db = 2000.0, 0.5, 1.0, 0.0  # [ENGINE] resource defaults
                 if k == FX_EARLY_REFLECTIONS:
                     ring = np.zeros((er_ring_frames, 2), dtype=np.float32)
                     self._rings.append(ring)
                     pd.fx[j].ring = ring.ctypes.data_as(C.POINTER(Frame))
                     pd.fx[j].ring_frames = er_ring_frames
+
+    def set_fx_settings(self, s, j, cutoff_hz=None, resonance=None, gain=None, volume_db=None):
+        """What a script sets on effect j's resource for source s (the GAS_FX_LOWPASS .. GAS_FX_AMPLIFY kinds)."""
+        fx = self.states[s].pdfx.fx[j]
+        for name, v in (("cutoff_hz", cutoff_hz), ("resonance", resonance), ("gain", gain), ("volume_db", volume_db)):
+            if v is not None:
+                setattr(fx, name, float(v))
 
     def block(self, params, src, want64=False):
         """params: PARAMS_DTYPE[n_src]; src: float32 [n_src][F][2]. Returns (mix [C][F][2], peaks [n_src][2], mix64|None)."""

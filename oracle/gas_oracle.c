@@ -234,6 +234,114 @@ void gaso_mix_channel_3d(const gaso_params *params, gaso_pdata3d *pd, int channe
 /* Effects                                                              */
 /* ------------------------------------------------------------------ */
 
+/* [ENGINE] AudioFilterSW::prepare_coefficients, the modes AudioEffectFilter's other subclasses select (recollection of
+ * servers/audio/audio_filter_sw.cpp -- unpinned): LOWPASS, HIGHPASS, BANDPASS (Q doubled), NOTCH,
+ * LOWSHELF, stages = 1.  RBJ cookbook forms; tests/test_oracle_primitives.py pins them against scipy. */
+void gaso_filter_coeffs(int kind, double sampling_rate, double cutoff, double resonance, double gain, gaso_coeffs *out) {
+	int sr_limit = (int)(sampling_rate / 2) + 512;
+	double final_cutoff = (cutoff > sr_limit) ? sr_limit : cutoff;
+	if (final_cutoff < 1) {
+		final_cutoff = 1;
+	}
+	double omega = 6.2831853071795864769252867666 * final_cutoff / sampling_rate;
+	double sin_v = sin(omega);
+	double cos_v = cos(omega);
+	double Q = resonance;
+	if (Q <= 0.0) {
+		Q = 0.0001;
+	}
+	if (kind == GASO_FX_BANDPASS) {
+		Q *= 2.0;
+	}
+	double tmpgain = gain;
+	if (tmpgain < 0.001) {
+		tmpgain = 0.001;
+	}
+	double alpha = sin_v / (2 * Q);
+	double a0 = 1.0 + alpha;
+	switch (kind) {
+		case GASO_FX_LOWPASS:
+			out->b0 = (float)((1.0 - cos_v) / 2.0);
+			out->b1 = (float)(1.0 - cos_v);
+			out->b2 = (float)((1.0 - cos_v) / 2.0);
+			out->a1 = (float)(-2.0 * cos_v);
+			out->a2 = (float)(1.0 - alpha);
+			break;
+		case GASO_FX_HIGHPASS:
+			out->b0 = (float)((1.0 + cos_v) / 2.0);
+			out->b1 = (float)(-(1.0 + cos_v));
+			out->b2 = (float)((1.0 + cos_v) / 2.0);
+			out->a1 = (float)(-2.0 * cos_v);
+			out->a2 = (float)(1.0 - alpha);
+			break;
+		case GASO_FX_BANDPASS:
+			out->b0 = (float)(alpha * sqrt(Q + 1));
+			out->b1 = 0.0f;
+			out->b2 = (float)(-alpha * sqrt(Q + 1));
+			out->a1 = (float)(-2.0 * cos_v);
+			out->a2 = (float)(1.0 - alpha);
+			break;
+		case GASO_FX_NOTCH:
+			out->b0 = 1.0f;
+			out->b1 = (float)(-2.0 * cos_v);
+			out->b2 = 1.0f;
+			out->a1 = (float)(-2.0 * cos_v);
+			out->a2 = (float)(1.0 - alpha);
+			break;
+		default: { /* GASO_FX_LOWSHELF */
+			double tmpq = sqrt(Q);
+			if (tmpq <= 0) {
+				tmpq = 0.001;
+			}
+			double beta = sqrt(tmpgain) / tmpq;
+			a0 = (tmpgain + 1.0) + (tmpgain - 1.0) * cos_v + beta * sin_v;
+			out->b0 = (float)(tmpgain * ((tmpgain + 1.0) - (tmpgain - 1.0) * cos_v + beta * sin_v));
+			out->b1 = (float)(2.0 * tmpgain * ((tmpgain - 1.0) - (tmpgain + 1.0) * cos_v));
+			out->b2 = (float)(tmpgain * ((tmpgain + 1.0) - (tmpgain - 1.0) * cos_v - beta * sin_v));
+			out->a1 = (float)(-2.0 * ((tmpgain - 1.0) + (tmpgain + 1.0) * cos_v));
+			out->a2 = (float)((tmpgain + 1.0) + (tmpgain - 1.0) * cos_v - beta * sin_v);
+		} break;
+	}
+	out->b0 = (float)(out->b0 / a0);
+	out->b1 = (float)(out->b1 / a0);
+	out->b2 = (float)(out->b2 / a0);
+	out->a1 = (float)(out->a1 / (0.0 - a0));
+	out->a2 = (float)(out->a2 / (0.0 - a0));
+}
+
+/* [ENGINE] AudioEffectFilterInstance::process for the other filter resources at FILTER_6DB: settings read from the
+ * resource every block, coefficients snapped, process_one per ear (same shape as fx_highshelf below). */
+static void fx_filter(int kind, gaso_fx_state *st, const gaso_frame *src, gaso_frame *dst, int n, float mix_rate) {
+	gaso_coeffs target;
+	gaso_filter_coeffs(kind, mix_rate, st->cutoff_hz, st->resonance, st->gain, &target);
+	gaso_processor_update_coeffs(&st->shelf[0], &target, 0);
+	gaso_processor_update_coeffs(&st->shelf[1], &target, 0);
+	for (int i = 0; i < n; i++) {
+		dst[i].l = gaso_processor_process_one(&st->shelf[0], src[i].l);
+	}
+	for (int i = 0; i < n; i++) {
+		dst[i].r = gaso_processor_process_one(&st->shelf[1], src[i].r);
+	}
+}
+
+/* [ENGINE] AudioEffectAmplifyInstance::process (recollection of servers/audio/effects/audio_effect_amplify.cpp):
+ *   vol = db_to_linear(mix_volume_db); vol_inc = (db_to_linear(volume_db) - vol) / frame_count;
+ *   dst[i] = src[i] * vol; vol += vol_inc;   then mix_volume_db = volume_db. */
+static void fx_amplify(gaso_fx_state *st, const gaso_frame *src, gaso_frame *dst, int n) {
+	if (!st->amp_started) { /* instantiate(): mix_volume_db = volume_db */
+		st->amp_mix_volume_db = st->volume_db;
+		st->amp_started = 1;
+	}
+	float vol = gaso_db_to_linear(st->amp_mix_volume_db);
+	float vol_inc = (gaso_db_to_linear(st->volume_db) - vol) / (float)n;
+	for (int i = 0; i < n; i++) {
+		dst[i].l = src[i].l * vol;
+		dst[i].r = src[i].r * vol;
+		vol += vol_inc;
+	}
+	st->amp_mix_volume_db = st->volume_db;
+}
+
 /* [ENGINE] AudioEffectFilterInstance::process for AudioEffectHighShelfFilter at
  * FILTER_6DB: coefficients snapped every call (update_coeffs() with no
  * interpolation), process_one over all left samples then all right samples
@@ -349,6 +457,16 @@ void gaso_fx_process(int kind, const gaso_params *params, gaso_fx_state *st, con
 			break;
 		case GASO_FX_EARLY_REFLECTIONS:
 			fx_early_reflections(params, st, src, dst, n);
+			break;
+		case GASO_FX_LOWPASS:
+		case GASO_FX_HIGHPASS:
+		case GASO_FX_BANDPASS:
+		case GASO_FX_NOTCH:
+		case GASO_FX_LOWSHELF:
+			fx_filter(kind, st, src, dst, n, mix_rate);
+			break;
+		case GASO_FX_AMPLIFY:
+			fx_amplify(st, src, dst, n);
 			break;
 		case GASO_FX_HRTF:
 			if (hrtf->impl == 1) {
@@ -562,7 +680,7 @@ void gaso_mix_from_playback_list(gaso_instance *inst, const gaso_params *const *
 	}
 	for (int p = 0; p < n_playbacks; p++) { /* :353 */
 		gaso_playback *pb = playbacks[p];
-		if (!pb->active) { /* :355-357 */
+		if (!pb->active || pb->paused) { /* :355-357; paused: see gaso_playback */
 			continue;
 		}
 		gaso_frame *buf = inst->playback_buffer;

@@ -83,6 +83,14 @@ enum {
 	GASO_FX_HIGHSHELF = 1, /* [ENGINE] AudioEffectHighShelfFilter, FILTER_6DB (gd_spatializer.gd:14-19) */
 	GASO_FX_EARLY_REFLECTIONS = 2, /* NEW */
 	GASO_FX_HRTF = 3, /* NEW */
+	/* audio_spatializer_effect.cpp:79-88 instantiates any AudioEffect: the engine's other one-biquad filters
+	 * ([ENGINE] AudioEffectFilter subclasses, FILTER_6DB) and AudioEffectAmplify */
+	GASO_FX_LOWPASS = 4,
+	GASO_FX_HIGHPASS = 5,
+	GASO_FX_BANDPASS = 6,
+	GASO_FX_NOTCH = 7,
+	GASO_FX_LOWSHELF = 8,
+	GASO_FX_AMPLIFY = 9,
 };
 
 /* audio_spatializer_effect.h:68-76 SpatializerPlaybackDataEffect: one effect
@@ -98,6 +106,13 @@ typedef struct gaso_fx_state {
 	float hist[GASO_HRTF_TAPS - 1];
 	float prev_gain;
 	int32_t prev_dir_plus1; /* 0 = no previous callback yet; else previous hrtf_dir + 1 (cross-fade) */
+	/* LOWPASS .. LOWSHELF: the settings the instance reads from its resource every block ([ENGINE] AudioEffectFilter:
+	 * cutoff 2000, resonance 0.5, gain 1 by default); the processors are shelf[] above */
+	float cutoff_hz, resonance, gain;
+	/* AMPLIFY: [ENGINE] AudioEffectAmplify::volume_db, the instance's mix_volume_db and whether a block has run (the
+	 * instance is created with mix_volume_db = volume_db) */
+	float volume_db, amp_mix_volume_db;
+	int32_t amp_started;
 } gaso_fx_state;
 
 typedef struct gaso_pdata_effect {
@@ -122,6 +137,8 @@ typedef struct gaso_hrtf {
 float gaso_db_to_linear(float db);
 float gaso_linear_to_db(float lin);
 void gaso_highshelf_coeffs(double sampling_rate, double cutoff, double resonance, double gain, int stages, gaso_coeffs *out);
+/* the other AudioFilterSW modes (kind = GASO_FX_LOWPASS .. GASO_FX_LOWSHELF), one stage */
+void gaso_filter_coeffs(int kind, double sampling_rate, double cutoff, double resonance, double gain, gaso_coeffs *out);
 void gaso_processor_update_coeffs(gaso_processor *p, const gaso_coeffs *target, int interp_len);
 float gaso_processor_process_one(gaso_processor *p, float x);
 float gaso_processor_process_one_interp(gaso_processor *p, float x);
@@ -159,7 +176,7 @@ typedef struct gaso_playback {
 	gaso_pdata_effect pdfx;
 	float last_peak[2];
 	int32_t resampled;
-	int32_t pad_;
+	int32_t paused; /* NEW (batched host): a paused playback is neither sampled nor mixed, keeps its state and is not gated.  The reference pauses an instance's own proxies on AudioServer (audio_spatializer.cpp:115-122); with one shared proxy per bus the pause has to live per playback */
 	uint64_t mix_offset; /* resampled: position in the stream, 16.16 fixed point */
 } gaso_playback;
 

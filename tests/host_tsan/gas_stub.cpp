@@ -14,6 +14,8 @@ struct gas_ctx {
 	gas_config cfg{};
 	std::vector<int> used; // plain state: audio-thread only
 	std::vector<gas_params> params;
+	uint32_t last_stream_n = 0;
+	std::mutex alloc_mu;
 	std::mutex params_mu;
 	std::atomic<unsigned long> blocks{ 0 }; // read by the driver thread
 	unsigned long allocs = 0, frees = 0;
@@ -47,6 +49,7 @@ int gas_ctx_get_config(gas_ctx *c, gas_config *out) {
 }
 
 int gas_source_alloc(gas_ctx *c, int, const int32_t *, uint32_t, uint32_t *out_slot) {
+	std::lock_guard<std::mutex> lk(c->alloc_mu); // like the real allocator: open to every thread
 	for (uint32_t s = 0; s < c->cfg.max_sources; s++) {
 		if (!c->used[s]) {
 			c->used[s] = 1;
@@ -59,6 +62,7 @@ int gas_source_alloc(gas_ctx *c, int, const int32_t *, uint32_t, uint32_t *out_s
 }
 
 int gas_source_free(gas_ctx *c, uint32_t slot) {
+	std::lock_guard<std::mutex> lk(c->alloc_mu);
 	if (slot >= c->cfg.max_sources || !c->used[slot]) {
 		return GAS_ERR_BAD_SLOT;
 	}
@@ -115,6 +119,17 @@ int gas_process_block_streams(gas_ctx *c, const uint32_t *, uint32_t n, uint32_t
 	for (uint32_t r = 0; r < n; r++) {
 		peaks[2 * r] = peaks[2 * r + 1] = 0.0f;
 		has_frames[r] = 0; // every device stream "ends" at once: exercises the gate + reap path
+	}
+	c->last_stream_n = n;
+	return GAS_OK;
+}
+
+int gas_stream_positions(gas_ctx *c, uint32_t n, uint64_t *out_frames) {
+	if (n != c->last_stream_n) {
+		return GAS_ERR_INVALID_ARGUMENT;
+	}
+	for (uint32_t r = 0; r < n; r++) {
+		out_frames[r] = c->cfg.frames;
 	}
 	return GAS_OK;
 }

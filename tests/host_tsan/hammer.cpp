@@ -24,6 +24,21 @@ static int counting_feed(void *user, gas_audio_frame *buf, float, int frames) {
 	return got;
 }
 
+static std::atomic<int> released{ 0 }, hooked{ 0 };
+
+static void on_release(void *, uint32_t, void *user) { // control threads only; `user` may be freed from here on
+	if (user) {
+		*static_cast<int *>(user) = -1; // would race with counting_feed if the host still called it
+	}
+	released++;
+}
+
+static int effects_hook(void *, uint32_t id, gas_params *p) { // audio thread
+	hooked++;
+	p->fx_shelf_gain = 0.5f + (float)(id & 3);
+	return (id & 1) != 0;
+}
+
 int main(int argc, char **argv) {
 	const int rounds = argc > 1 ? atoi(argv[1]) : 1500;
 	const int device_mode = argc > 2 ? atoi(argv[2]) : 0;
@@ -38,6 +53,8 @@ int main(int argc, char **argv) {
 	std::atomic<bool> stop{ false };
 	std::atomic<uint32_t> newest{ 0 };
 	std::atomic<int> failures{ 0 };
+	gas_host_set_release_fn(host, on_release, nullptr);
+	gas_host_set_process_effects_fn(host, effects_hook, nullptr);
 
 	std::thread audio([&] {
 		std::vector<gas_audio_frame> out(F);
@@ -60,8 +77,21 @@ int main(int argc, char **argv) {
 				p.hrtf_gain = 0.5f;
 				gas_host_set_spatializer_parameters(host, id, &p);
 				(void)gas_host_is_playback_active(host, id);
+				// pause / resume / position from the second control thread (audio_spatializer.cpp:115-122, :144-170)
+				gas_host_set_playback_paused(host, id, (id & 2) != 0);
+				(void)gas_host_is_playback_paused(host, id);
+				uint64_t pos = 0;
+				(void)gas_host_get_playback_position(host, id, &pos);
+				gas_host_set_playback_paused(host, id, 0);
+			}
+			// the context's slot allocator is open to control threads too (gas_amd.h): a throw-away slot per loop
+			uint32_t probe = 0;
+			if (gas_source_alloc(ctx, GAS_KIND_EFFECT, nullptr, 0, &probe) == GAS_OK) {
+				gas_source_free(ctx, probe);
 			}
 			(void)gas_host_playback_count(host);
+			(void)gas_host_collect_released(host);
+			gas_host_set_process_effects_fn(host, effects_hook, nullptr); // re-registering while the audio thread runs
 			gas_host_set_playback_disable_threshold_db(host, -80.0f);
 		}
 	});
@@ -106,8 +136,8 @@ int main(int argc, char **argv) {
 	audio.join();
 	physics.join();
 	const int left = gas_host_playback_count(host);
-	printf("callbacks %lu, playbacks left %d, failures %d\n", gas_stub_blocks(ctx), left, failures.load());
 	gas_host_destroy(host);
+	printf("callbacks %lu, playbacks left %d, failures %d, released %d of %d, hook calls %d\n", gas_stub_blocks(ctx), left, failures.load(), released.load(), rounds, hooked.load());
 	gas_stub_ctx_destroy(ctx);
-	return (left == 0 && failures.load() == 0) ? 0 : 1;
+	return (left == 0 && failures.load() == 0 && released.load() == rounds && hooked.load() > 0) ? 0 : 1;
 }

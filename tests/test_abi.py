@@ -27,13 +27,23 @@ def test_library_exports_every_declared_symbol(gas):
     assert lib.gas_abi_version() == 2
 
 
+def test_library_exports_the_host_layer_surface(gas):
+    lib = gas.load_library()
+    src = open(os.path.join(ROOT, "include", "gas_amd_host.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    declared = sorted(set(re.findall(r"\b(gas_(?:host|multi)_[a-z0-9_]+)\s*\(", src)))
+    assert "gas_host_set_playback_paused" in declared and "gas_host_get_playback_position" in declared
+    missing = [f for f in declared if f != "gas_host_stream_mix_fn" and not hasattr(lib, f)]
+    assert not missing, missing
+
+
 def test_pod_layouts(gas):
     assert gas.capi.PARAMS_DTYPE.itemsize == 128
     assert gas.capi.PARAMS_DTYPE.fields["hrtf_gain"][1] == 48
     assert gas.capi.PARAMS_DTYPE.fields["er_gain"][1] == 64
     assert gas.capi.PARAMS_DTYPE.fields["er_delay"][1] == 96
     assert C.sizeof(gas.capi.Config) == 32
-    assert C.sizeof(gas.capi.Profile) == 8 + 8 + 8 + 64
+    assert C.sizeof(gas.capi.Profile) == 8 + 8 + 8 + 64 + 4 + 4 + 8
 
 
 def test_strerror_covers_every_status(gas):

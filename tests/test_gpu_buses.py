@@ -39,7 +39,7 @@ def test_buses_match_per_source_bus_maps(gas, ob, n, channels, n_buses):
             p["mix_volumes"][::11] = 0.0  # silent pairs: the send is 0 there (mix volume <= 0, :300-305)
             # reverb send volumes per source and pair (what calculate_spatialization's reverb_vol would give)
             reverb = (p["mix_volumes"] * rng.uniform(0.0, 1.5, (n, 1, 1))).astype(np.float32)
-            routes = np.zeros(n, K.BUS_ROUTE_DTYPE)
+            routes = K.bus_routes(n)
             routes["dry_bus"] = rng.integers(0, n_buses, n)  # the player's bus or an Area3D override
             routes["send_bus"] = np.where(rng.uniform(size=n) < 0.6, rng.integers(0, n_buses, n), K.BUS_NONE)
             for s in range(n):
@@ -79,7 +79,7 @@ def test_buses_without_sends_sum_to_the_single_mix(gas):
     rng = np.random.default_rng(4)
     p = synth.draw_params(rng, n, frames=F)
     src = synth.draw_sources(rng, n, F)
-    routes = np.zeros(n, K.BUS_ROUTE_DTYPE)
+    routes = K.bus_routes(n)
     routes["dry_bus"] = rng.integers(0, 4, n)
     routes["send_bus"] = K.BUS_NONE
     outs = []
@@ -131,7 +131,7 @@ def test_effect_kinds_route_to_buses(gas, ob, chain_name, n, n_buses, F):
         whole = ob.BatchOracle(ob.KIND_EFFECT, n, F, chain=list(chain), hrir=hrir, er_ring_frames=max(ring, 1))
         for cb in range(3):
             p = synth.draw_params(rng, n, dirs=dirs, ring_frames=max(ring, 2 * F), frames=F)
-            routes = np.zeros(n, K.BUS_ROUTE_DTYPE)
+            routes = K.bus_routes(n)
             routes["dry_bus"] = rng.integers(0, n_buses, n)
             routes["send_bus"] = np.where(rng.uniform(size=n) < 0.6, rng.integers(0, n_buses, n), K.BUS_NONE)
             routes["send"][:, 0, :] = rng.uniform(0.0, 1.2, (n, 2)).astype(np.float32)
@@ -167,7 +167,7 @@ def test_effect_buses_without_sends_sum_to_the_single_mix(gas):
     hrir = synth.synthetic_hrir(np.random.default_rng(7), dirs=dirs)
     p = synth.draw_params(rng, n, dirs=dirs, frames=F)
     src = synth.draw_sources(rng, n, F)
-    routes = np.zeros(n, K.BUS_ROUTE_DTYPE)
+    routes = K.bus_routes(n)
     routes["dry_bus"] = rng.integers(0, 3, n)
     routes["send_bus"] = K.BUS_NONE
     outs = []
@@ -204,7 +204,7 @@ def test_bus_call_reuses_the_list(gas):
         ctx.hrtf_load(hrir)
         slots = ctx.source_alloc_many(n, K.KIND_EFFECT, (K.FX_HRTF,))
         ctx.params_publish_batch(slots, synth.draw_params(rng, n, dirs=32, frames=F))
-        routes = np.zeros(n, K.BUS_ROUTE_DTYPE)
+        routes = K.bus_routes(n)
         routes["send_bus"] = 1
         routes["send"][:, 0, :] = 0.25
         ctx.bus_routes_publish(slots, routes)
@@ -248,7 +248,7 @@ def test_fused_two_bus_form_bus_sums_against_the_oracle_at_size(gas, ob, peaks_m
     n, F, dirs, n_buses = 2304 + 77, 512, 40, 2
     rng = np.random.default_rng(21)
     hrir = synth.synthetic_hrir(np.random.default_rng(7), dirs=dirs)
-    routes = np.zeros(n, K.BUS_ROUTE_DTYPE)
+    routes = K.bus_routes(n)
     routes["dry_bus"] = rng.integers(0, n_buses, n)
     routes["send_bus"] = np.where(rng.uniform(size=n) < 0.7, rng.integers(0, n_buses, n), K.BUS_NONE)
     routes["send"][:, 0, :] = rng.uniform(0.0, 1.2, (n, 2)).astype(np.float32)
@@ -284,3 +284,54 @@ def test_fused_two_bus_form_bus_sums_against_the_oracle_at_size(gas, ob, peaks_m
                     q["hrtf_gain"] = (p["hrtf_gain"] * w[b, ear]).astype(np.float32)
                     _, _, y64 = scaled[b][ear].block(q.astype(ob.PARAMS_DTYPE), src, want64=True)
                     assert rel_rms(got[b, 0, :, ear], y64[0, :, ear]) <= TOL, (cb, b, ear)
+
+
+@pytest.mark.parametrize("kind_name,chain,channels", [("KIND_3D_MIX", (), 2), ("KIND_EFFECT", (3,), 1), ("KIND_EFFECT", (1, 3), 1)])
+def test_up_to_six_buses_per_playback(gas, ob, kind_name, chain, channels):
+    """audio_spatializer.cpp:283-287 walks EVERY key of bus_volumes, up to MAX_BUSES_PER_PLAYBACK = 6: a playback's dry
+    bus plus up to five sends (gas_bus_route.more_bus / more_send).  Oracle: per-source outputs, multiplied per bus the
+    way AudioServer does ([ENGINE] frame * volume, f32) and summed in f64."""
+    from godot_audio_spatializer_amd import synth
+
+    K = gas.capi
+    kind = getattr(K, kind_name)
+    okind = getattr(ob, kind_name)
+    F, n, n_buses = 512, 90, 6
+    rng = np.random.default_rng(17)
+    hrir = synth.synthetic_hrir(rng, dirs=16) if 3 in chain else None
+    with gas.SpatializerContext(max_sources=n, frames=F, channel_count=channels) as ctx:
+        if hrir is not None:
+            ctx.hrtf_load(hrir)
+        slots = ctx.source_alloc_many(n, kind, chain)
+        oracles = [ob.BatchOracle(okind, 1, F, channel_count=channels, chain=chain, hrir=hrir) for _ in range(n)]
+        for cb in range(3):
+            p = synth.draw_params(rng, n, dirs=16, channel_count=channels, frames=F)
+            routes = K.bus_routes(n)
+            routes["dry_bus"] = rng.integers(0, n_buses, n)
+            n_sends = rng.integers(0, 6, n)  # 0..5 sends
+            for s in range(n):
+                order = rng.permutation(n_buses)  # distinct target buses, like dictionary keys; may include the dry bus
+                for k in range(n_sends[s]):
+                    vol = rng.uniform(0.0, 1.2, (K.MAX_CHANNELS, 2)).astype(np.float32)
+                    if k == 0:
+                        routes["send_bus"][s], routes["send"][s] = order[k], vol
+                    else:
+                        routes["more_bus"][s, k - 1], routes["more_send"][s, k - 1] = order[k], vol
+            ctx.params_publish_batch(slots, p)
+            ctx.bus_routes_publish(slots, routes)
+            src = synth.draw_sources(rng, n, F)
+            got, peaks = ctx.process_block_buses(src, slots, n_buses)
+            want = np.zeros((n_buses, channels, F, 2), np.float64)
+            for s in range(n):
+                _, pk, y = oracles[s].block(p[s:s + 1].astype(ob.PARAMS_DTYPE), src[s:s + 1], want64=True)
+                np.testing.assert_allclose(peaks[s], pk[0], rtol=2e-5, atol=1e-7)
+                y32 = y[:channels].astype(np.float32)
+                want[routes["dry_bus"][s]] += y32
+                sends = [(routes["send_bus"][s], routes["send"][s])] + [(routes["more_bus"][s, k], routes["more_send"][s, k]) for k in range(K.MAX_MORE_SENDS)]
+                for bus, vol in sends:
+                    if bus != K.BUS_NONE:
+                        for c in range(channels):
+                            want[bus, c] += (y32[c] * vol[c][None, :]).astype(np.float32)
+            for b in range(n_buses):
+                for c in range(channels):
+                    assert rel_rms(got[b, c], want[b, c]) <= TOL, (cb, b, c)

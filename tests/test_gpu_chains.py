@@ -112,5 +112,95 @@ def test_unsupported_chains_still_fail_loudly(gas):
     with pytest.raises(gas.GasError):
         ctx.source_alloc_many(1, K.KIND_EFFECT, (HRTF, HS, HRTF))  # one HRTF history per playback
     with pytest.raises(gas.GasError):
-        ctx.source_alloc_many(1, K.KIND_EFFECT, (HS, 9))
+        ctx.source_alloc_many(1, K.KIND_EFFECT, (HS, 10))  # no such effect kind
     ctx.close()
+
+
+LP, HP, BP, NOTCH, LSH, AMP = 4, 5, 6, 7, 8, 9
+
+
+@pytest.mark.parametrize(
+    "chain,frames",
+    [
+        ((LP,), 512),
+        ((HP, HRTF), 512),
+        ((AMP,), 256),
+        ((BP, AMP, HRTF), 256),
+        ((NOTCH, LSH), 512),
+        ((AMP, HS, LP, AMP), 128),
+        ((ER, LP), 256),
+    ],
+)
+def test_engine_effect_kinds_match_oracle(gas, ob, chain, frames):
+    """further AudioEffect kinds behind the chain (audio_spatializer_effect.cpp:79-88 instantiates any
+    AudioEffect): the engine's other one-biquad filters and the amplifier, settings per playback and chain position
+    (gas_fx_settings), re-published between callbacks as a _process_effects script would."""
+    from godot_audio_spatializer_amd import synth
+
+    n, ring = 75, 4096 if ER in chain else 0
+    hrir = _hrir() if HRTF in chain else None
+    rng = np.random.default_rng(21)
+    with gas.SpatializerContext(max_sources=n + 4, frames=frames, er_ring_frames=ring) as ctx:
+        if hrir is not None:
+            ctx.hrtf_load(hrir)
+        slots = ctx.source_alloc_many(n, gas.capi.KIND_EFFECT, chain)
+        ora = ob.BatchOracle(ob.KIND_EFFECT, n, frames, chain=chain, hrir=hrir, er_ring_frames=max(ring, 1))
+        for b in range(9):
+            if b % 3 == 0:
+                p = synth.draw_params(rng, n, dirs=32, ring_frames=max(ring, 2 * frames), frames=frames)
+                ctx.params_publish_batch(slots, p)
+            if b in (1, 2, 5, 7):  # block 0 runs on the resource defaults; then the settings move, for some sources only
+                who = np.arange(n) if b == 1 else rng.choice(n, n // 2, replace=False)
+                st = ctx.fx_settings_defaults(len(who))
+                st["filter_cutoff_hz"] = np.exp(rng.uniform(np.log(80.0), np.log(12000.0), (len(who), 4)))
+                st["filter_resonance"] = rng.uniform(0.3, 2.0, (len(who), 4))
+                st["filter_gain"] = np.exp(rng.uniform(np.log(0.1), np.log(3.0), (len(who), 4)))
+                st["amplify_volume_db"] = rng.uniform(-18.0, 6.0, (len(who), 4))
+                ctx.fx_settings_publish(slots[who], st)
+                for k, s in enumerate(who):
+                    for j in range(len(chain)):
+                        ora.set_fx_settings(int(s), j, st["filter_cutoff_hz"][k, j], st["filter_resonance"][k, j], st["filter_gain"][k, j], st["amplify_volume_db"][k, j])
+            src = synth.draw_sources(rng, n, frames)
+            mix, peaks = ctx.process_block(src, slots)
+            _, rpeaks, r64 = ora.block(p.astype(ob.PARAMS_DTYPE), src, want64=True)
+            assert rel_rms(mix[0], r64[0]) <= TOL, f"block {b}"
+            # a recursive filter BEHIND early reflections / the FFT amplifies their last-bit differences from the oracle by
+            # ~1 / (1 - r^2) (r = pole radius: 190x at 80 Hz, Q = 2): a single source's peak is then good to 1e-4, the mix
+            # (errors average over sources and frames) still to TOL
+            seen_new = False
+            loose = False
+            for k in chain:
+                loose = loose or (seen_new and LP <= k <= LSH)
+                seen_new = seen_new or k in (ER, HRTF)
+            np.testing.assert_allclose(peaks, rpeaks, rtol=2e-4 if loose else 2e-5, atol=1e-7)
+
+
+def test_engine_effect_settings_do_not_survive_a_slot(gas, ob):
+    """A freed slot handed to a new playback starts from the resource defaults again (effect instances are created per
+    playback, audio_spatializer_effect.cpp:79-88)."""
+    from godot_audio_spatializer_amd import synth
+
+    F = 256
+    rng = np.random.default_rng(2)
+    with gas.SpatializerContext(max_sources=2, frames=F) as ctx:
+        p = synth.draw_params(rng, 1, dirs=8)
+        src = synth.draw_sources(rng, 1, F)
+        other = ctx.source_alloc_many(1, gas.capi.KIND_EFFECT, ())
+        ctx.params_publish_batch(other, p)
+        s0 = ctx.source_alloc_many(1, gas.capi.KIND_EFFECT, (AMP,))
+        st = ctx.fx_settings_defaults(1)
+        st["amplify_volume_db"] = -20.0
+        ctx.fx_settings_publish(s0, st)
+        ctx.params_publish_batch(s0, p)
+        quiet, _ = ctx.process_block(src, s0)
+        np.testing.assert_allclose(quiet[0], src[0] * np.float32(0.1), rtol=2e-6)
+        ctx.source_free(int(s0[0]))
+        ctx.process_block(src, other)  # a block boundary: the free takes effect
+        s1 = ctx.source_alloc_many(1, gas.capi.KIND_EFFECT, (AMP,))
+        assert s1[0] == s0[0]
+        ctx.params_publish_batch(s1, p)
+        loud, _ = ctx.process_block(src, s1)
+        np.testing.assert_array_equal(loud[0], src[0])  # 0 dB, no ramp on a fresh instance
+    with pytest.raises(gas.GasError):
+        with gas.SpatializerContext(max_sources=2, frames=F) as ctx:
+            ctx.source_alloc_many(1, gas.capi.KIND_EFFECT, (10,))  # unknown kind

@@ -10,7 +10,8 @@ from test_oracle_mixer import Rig
 pytestmark = pytest.mark.gpu
 
 
-def drive(gas, ob, kind, okind, chain, ochain, channel_count, lengths, F, callbacks, hrir=None, stop_at=None, seed=0, device_streams=False):
+def drive(gas, ob, kind, okind, chain, ochain, channel_count, lengths, F, callbacks, hrir=None, stop_at=None, seed=0, device_streams=False, pause_plan=None):
+    """pause_plan: {callback: [(playback index, paused), ...]} applied before that callback on both sides."""
     from godot_audio_spatializer_amd import synth
 
     rng = np.random.default_rng(seed)
@@ -35,6 +36,9 @@ def drive(gas, ob, kind, okind, chain, ochain, channel_count, lengths, F, callba
             if stop_at and cb == stop_at[0]:
                 host.stop_playback(ids[stop_at[1]])
                 rig.pbs[stop_at[1]].active = 0
+            for i, paused in (pause_plan or {}).get(cb, ()):
+                assert host.set_playback_paused(ids[i], paused) == 0
+                rig.pbs[i].paused = int(paused)
             for c in range(C):
                 rc, got = host.get_mixed_frames(c, F)
                 orc, want = rig.get_mixed_frames(c)
@@ -42,6 +46,9 @@ def drive(gas, ob, kind, okind, chain, ochain, channel_count, lengths, F, callba
                 assert mix_matches(got, want), f"callback {cb} channel {c}"
             for i in range(len(lengths)):
                 assert host.is_playback_active(ids[i]) == bool(rig.pbs[i].active), f"callback {cb} playback {i}"
+                if rig.pbs[i].active:  # get_playback_position (audio_spatializer.cpp:144-157): frames consumed, lookahead included
+                    assert host.is_playback_paused(ids[i]) == bool(rig.pbs[i].paused)
+                    assert host.get_playback_position(ids[i]) == rig.pbs[i].stream_pos, f"callback {cb} playback {i}"
         n_alive = sum(int(rig.pbs[i].active) for i in range(len(lengths)))
         assert host.playback_count() == n_alive  # inactive nodes were reaped (audio_spatializer.cpp:473-482)
         # errors mirror :521-522
@@ -76,6 +83,115 @@ def test_host_device_stream_mode(gas, ob):
     hrir = synth.synthetic_hrir(np.random.default_rng(7), dirs=8)
     drive(gas, ob, gas.capi.KIND_EFFECT, ob.KIND_EFFECT, (gas.capi.FX_HRTF,), (ob.FX_HRTF,), 1, [600, 1500, 4000, 2048], 512, 10, hrir=hrir, device_streams=True)
     drive(gas, ob, gas.capi.KIND_3D_MIX, ob.KIND_3D_MIX, (), (), 2, [900, 3000, 2000], 512, 7, device_streams=True, stop_at=(3, 1))
+
+
+@pytest.mark.parametrize("device_streams", [False, True])
+def test_host_pause_resume_per_playback(gas, ob, device_streams):
+    """set_playback_paused per playback (audio_spatializer.cpp:115-122 moved from the proxies to the playback): pause
+    mid-stream, resume, pause during the HRIR ring-out; a paused playback keeps its state, lookahead and position, is
+    neither gated nor reaped, and the others play on."""
+    from godot_audio_spatializer_amd import synth
+
+    hrir = synth.synthetic_hrir(np.random.default_rng(7), dirs=8)
+    plan = {
+        1: [(1, True)],  # mid-stream
+        2: [(0, True)],  # ringing out: its 600-frame stream ended in callback 1, the gate would take it after callback 2
+        3: [(1, False)],
+        5: [(0, False)],  # rings out now
+        6: [(2, True)],
+        8: [(2, False)],
+    }
+    drive(gas, ob, gas.capi.KIND_EFFECT, ob.KIND_EFFECT, (gas.capi.FX_HRTF,), (ob.FX_HRTF,), 1, [600, 1500, 4000, 2048], 512, 14, hrir=hrir, pause_plan=plan, device_streams=device_streams)
+    drive(gas, ob, gas.capi.KIND_3D_MIX, ob.KIND_3D_MIX, (), (), 2, [900, 3000, 2000], 512, 11, pause_plan={1: [(0, True), (2, True)], 4: [(0, False)], 5: [(2, False)]}, device_streams=device_streams)
+
+
+def test_host_pause_of_everything_gives_silence_and_keeps_the_list(gas, ob):
+    F = 512
+    with gas.SpatializerContext(max_sources=4, frames=F) as ctx:
+        host = gas.capi.BatchedSpatializerHost(ctx, gas.capi.KIND_EFFECT)
+        ids = [host.start_playback_array(np.full((4 * F, 2), 0.25, np.float32)) for _ in range(2)]
+        p = np.zeros(1, gas.capi.PARAMS_DTYPE)
+        for i in ids:
+            host.set_spatializer_parameters(i, p[0])
+        rc, a = host.get_mixed_frames(0, F)
+        assert rc == 0 and a[64:].any()
+        for i in ids:
+            host.set_playback_paused(i, True)
+        pos = [host.get_playback_position(i) for i in ids]
+        for _ in range(3):
+            rc, m = host.get_mixed_frames(0, F)
+            assert rc == 0 and not m.any()
+        assert host.playback_count() == 2 and all(host.is_playback_active(i) and host.is_playback_paused(i) for i in ids)
+        assert [host.get_playback_position(i) for i in ids] == pos
+        assert host.set_playback_paused(12345, True) == -3 and not host.is_playback_paused(12345)  # unknown id (audio_spatializer.cpp:161-170: false)
+        assert host.get_playback_position(12345) == 0  # :152-155
+        host.set_playback_paused(ids[0], False)
+        rc, m = host.get_mixed_frames(0, F)
+        np.testing.assert_array_equal(m[:, 0], np.full(F, 0.25, np.float32))  # resumes where it stopped: no new start silence
+        host.close()
+
+
+def test_host_process_effects_hook_and_release(gas, ob):
+    """_process_effects (audio_spatializer_effect.cpp:39,90-92): the example sets its high-shelf's gain from the
+    spatializer parameters on the audio thread (gd_spatializer_instance.gd:125-127).  Here the hook edits the playback's
+    parameter row; the result must be what the oracle gives with the edited rows.  Plus the release callback that stands
+    in for the list node's Ref<AudioStreamPlayback> (audio_spatializer.cpp:538-547)."""
+    from godot_audio_spatializer_amd import synth
+
+    F, n = 512, 3
+    rng = np.random.default_rng(5)
+    streams = [rng.uniform(-0.5, 0.5, (m, 2)).astype(np.float32) for m in (3000, 3000, 1200)]
+    params = synth.draw_params(rng, n, dirs=8)
+    params["fx_shelf_gain"] = 1.0
+    params["fx_shelf_cutoff_hz"] = 3000.0
+    cursors = [0] * n
+
+    with gas.SpatializerContext(max_sources=8, frames=F) as ctx:
+        host = gas.capi.BatchedSpatializerHost(ctx, gas.capi.KIND_EFFECT, (gas.capi.FX_HIGHSHELF,))
+        released, calls = [], []
+        host.set_release_fn(lambda pid, user: released.append((pid, user)))
+
+        def feed(i):
+            def mix(buf, rate, frames):
+                got = min(frames, len(streams[i]) - cursors[i])
+                buf[:got] = streams[i][cursors[i]: cursors[i] + got]
+                buf[got:] = 0.0
+                cursors[i] += got
+                return got
+
+            return mix
+
+        ids = [None] * n
+        for i in reversed(range(n)):
+            ids[i] = host.start_playback(feed(i), user=1000 + i)
+            host.set_spatializer_parameters(ids[i], params[i])
+
+        def hook(pid, row):
+            calls.append(pid)
+            if pid == ids[1]:
+                return False  # untouched: keeps gain 1
+            row["fx_shelf_gain"] = 0.25 + 0.5 * row["linear_attenuation"]
+            return True
+
+        host.set_process_effects_fn(hook)
+        rig = Rig(ob, ob.KIND_EFFECT, streams, F, chain=(ob.FX_HIGHSHELF,))
+        rig.params[:] = params.astype(ob.PARAMS_DTYPE)
+        for i in (0, 2):
+            rig.params["fx_shelf_gain"][i] = np.float32(0.25) + np.float32(0.5) * params["linear_attenuation"][i]
+        for cb in range(6):
+            if cb == 3:
+                host.set_process_effects_fn(None)  # the edited rows stay until the next set_spatializer_parameters
+                n_calls = len(calls)
+            rc, got = host.get_mixed_frames(0, F)
+            orc, want = rig.get_mixed_frames(0)
+            assert rc == 0 and orc == 0 and mix_matches(got, want), f"callback {cb}"
+        assert len(calls) == n_calls and set(calls) == set(ids)
+        assert not host.is_playback_active(ids[2]) and released == []  # reaped by the audio thread, not yet released
+        assert host.collect_released() == 1 and released == [(ids[2], 1002)]
+        host.stop_playback(ids[0])
+        host.get_mixed_frames(0, F)
+        host.close()  # destroy releases the rest
+        assert sorted(released) == sorted((ids[i], 1000 + i) for i in range(n))
 
 
 def test_host_modes_do_not_mix(gas):

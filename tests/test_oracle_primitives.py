@@ -259,3 +259,103 @@ def test_hrtf_crossfade_closed_form(ob):
         for ear in range(2):
             want = full[d][ear][sl] if prev == d else t * full[d][ear][sl] + (1 - t) * full[prev][ear][sl]
             assert rel_rms(outs[b][:, ear], want) < 5e-7, (b, ear)
+
+
+# ---- the other AudioFilterSW modes and AudioEffectAmplify (SURVEY 8f#4: further AudioEffect kinds) ------------------------
+# [ENGINE] recollection, unpinned like the rest of Appendix B; what is checked here shares no code with the oracle: the
+# RBJ cookbook forms written out in numpy, the transfer-function identities of each mode, scipy's lfilter.
+
+
+def _filter_coeffs(ob, kind, sr, fc, q, gain):
+    out = ob.Coeffs()
+    L = ob.lib()
+    L.gaso_filter_coeffs.argtypes = [C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, C.POINTER(ob.Coeffs)]
+    L.gaso_filter_coeffs.restype = None
+    L.gaso_filter_coeffs(kind, sr, fc, q, gain, C.byref(out))
+    return np.array([out.b0, out.b1, out.b2], np.float64), np.array([1.0, -out.a1, -out.a2], np.float64)  # feedback terms are stored negated
+
+
+def _rbj(kind, ob, sr, fc, q, A):
+    w = 2 * np.pi * fc / sr
+    cs, sn = np.cos(w), np.sin(w)
+    if kind == ob.FX_BANDPASS:
+        q = 2 * q
+    al = sn / (2 * q)
+    if kind == ob.FX_LOWPASS:
+        b, a = [(1 - cs) / 2, 1 - cs, (1 - cs) / 2], [1 + al, -2 * cs, 1 - al]
+    elif kind == ob.FX_HIGHPASS:
+        b, a = [(1 + cs) / 2, -(1 + cs), (1 + cs) / 2], [1 + al, -2 * cs, 1 - al]
+    elif kind == ob.FX_BANDPASS:  # the engine's variant: peak gain sqrt(Q + 1)
+        b, a = [al * np.sqrt(q + 1), 0.0, -al * np.sqrt(q + 1)], [1 + al, -2 * cs, 1 - al]
+    elif kind == ob.FX_NOTCH:
+        b, a = [1.0, -2 * cs, 1.0], [1 + al, -2 * cs, 1 - al]
+    else:  # low shelf, A passed as the linear gain itself, beta = sqrt(A) / sqrt(Q)
+        be = np.sqrt(A) / np.sqrt(q)
+        b = [A * ((A + 1) - (A - 1) * cs + be * sn), 2 * A * ((A - 1) - (A + 1) * cs), A * ((A + 1) - (A - 1) * cs - be * sn)]
+        a = [(A + 1) + (A - 1) * cs + be * sn, -2 * ((A - 1) + (A + 1) * cs), (A + 1) + (A - 1) * cs - be * sn]
+    return np.array(b) / a[0], np.array(a) / a[0]
+
+
+def _gain_at(b, a, w):
+    z = np.exp(-1j * w * np.arange(3))
+    return abs(np.dot(b, z) / np.dot(a, z))
+
+
+@pytest.mark.parametrize("kind_name", ["FX_LOWPASS", "FX_HIGHPASS", "FX_BANDPASS", "FX_NOTCH", "FX_LOWSHELF"])
+def test_filter_modes_match_rbj_and_their_identities(ob, kind_name):
+    kind = getattr(ob, kind_name)
+    sr, fc, q, A = 48000.0, 2000.0, 0.5, 0.4
+    b, a = _filter_coeffs(ob, kind, sr, fc, q, A)
+    rb, ra = _rbj(kind, ob, sr, fc, q, A)
+    np.testing.assert_allclose(b, rb, rtol=2e-6, atol=1e-9)
+    np.testing.assert_allclose(a, ra, rtol=2e-6, atol=1e-9)
+    assert np.all(np.abs(np.roots(a)) < 1.0)
+    w0 = 2 * np.pi * fc / sr
+    dc, nyq, at_fc = _gain_at(b, a, 0.0), _gain_at(b, a, np.pi), _gain_at(b, a, w0)
+    if kind == ob.FX_LOWPASS:
+        assert dc == pytest.approx(1.0, abs=1e-5) and nyq < 1e-6 and at_fc == pytest.approx(q, rel=1e-4)  # |H(w0)| = Q
+    elif kind == ob.FX_HIGHPASS:
+        assert dc < 1e-6 and nyq == pytest.approx(1.0, abs=1e-5) and at_fc == pytest.approx(q, rel=1e-4)
+    elif kind == ob.FX_BANDPASS:
+        assert dc < 1e-6 and nyq < 1e-6 and at_fc == pytest.approx(np.sqrt(2 * q + 1), rel=1e-4)
+    elif kind == ob.FX_NOTCH:
+        assert dc == pytest.approx(1.0, abs=1e-5) and nyq == pytest.approx(1.0, abs=1e-5) and at_fc < 1e-5
+    else:
+        assert dc == pytest.approx(A * A, rel=1e-3) and nyq == pytest.approx(1.0, abs=1e-4)  # the shelf lifts DC by A^2
+
+
+@pytest.mark.parametrize("kind_name", ["FX_LOWPASS", "FX_HIGHPASS", "FX_BANDPASS", "FX_NOTCH", "FX_LOWSHELF"])
+def test_filter_effects_are_lfilter_from_the_first_sample(ob, kind_name):
+    """[ENGINE] AudioEffectFilterInstance at FILTER_6DB: coefficients snapped every block, one processor per ear."""
+    kind = getattr(ob, kind_name)
+    F, rng = 256, np.random.default_rng(4)
+    ora = ob.BatchOracle(ob.KIND_EFFECT, 1, F, chain=[kind])
+    ora.set_fx_settings(0, 0, cutoff_hz=1500.0, resonance=0.8, gain=0.5)
+    p = params(ob, 1)
+    x = rng.uniform(-0.5, 0.5, (5, 1, F, 2)).astype(np.float32)
+    y = np.concatenate([ora.block(p, x[i])[0][0] for i in range(5)])
+    b, a = _filter_coeffs(ob, kind, 48000.0, 1500.0, 0.8, 0.5)
+    for ear in range(2):
+        ref = lfilter(b, a, x[:, 0, :, ear].reshape(-1).astype(np.float64))
+        assert rel_rms(y[:, ear], ref) < 5e-6
+
+
+def test_amplify_ramps_from_the_previous_volume(ob):
+    """[ENGINE] AudioEffectAmplify: vol ramps linearly from db_to_linear(previous volume_db) towards the new one and,
+    like the mix_channel lerp, stops one increment short of it; the first block has no ramp."""
+    F = 128
+    ora = ob.BatchOracle(ob.KIND_EFFECT, 1, F, chain=[ob.FX_AMPLIFY])
+    p = params(ob, 1)
+    x = np.ones((1, F, 2), np.float32)
+    ora.set_fx_settings(0, 0, volume_db=-6.0)
+    y0 = ora.block(p, x)[0][0]
+    v0 = 10.0 ** (-6.0 / 20.0)
+    np.testing.assert_allclose(y0, v0, rtol=1e-6)
+    ora.set_fx_settings(0, 0, volume_db=3.0)
+    y1 = ora.block(p, x)[0][0]
+    v1 = 10.0 ** (3.0 / 20.0)
+    ref = v0 + (v1 - v0) * np.arange(F) / F
+    np.testing.assert_allclose(y1[:, 0], ref, rtol=2e-5)
+    np.testing.assert_array_equal(y1[:, 0], y1[:, 1])
+    y2 = ora.block(p, x)[0][0]
+    np.testing.assert_allclose(y2, v1, rtol=1e-6)

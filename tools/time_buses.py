@@ -19,7 +19,7 @@ for name, kind, chain in (("[HRTF] fused two-bus form", K.KIND_EFFECT, (K.FX_HRT
     ctx.hrtf_load(synth.synthetic_hrir(rng, dirs=1024))
     slots = ctx.source_alloc_many(n, kind, chain)
     ctx.params_publish_batch(slots, synth.draw_params(rng, n, dirs=1024))
-    routes = np.zeros(n, K.BUS_ROUTE_DTYPE)
+    routes = K.bus_routes(n)
     routes["send_bus"] = 1
     routes["send"][:, 0, :] = 0.3
     ctx.bus_routes_publish(slots, routes)
