@@ -375,6 +375,73 @@ class Runner:
         self.ctx.close()
 
 
+def in_process_multi(env, devices, n_per_shard, callbacks=200, warmup=30):
+    """SURVEY 8e's single-process form (gas_multi_*): one context per entry of `devices`, every shard's partial mix
+    written all-to-one into the root's gather buffer, one ordered sum on the root -- per callback, i.e. the REAL-TIME
+    arrangement (no reduce bucket).  Device-resident shard inputs (gas_multi_process_block_mem(GAS_MEM_DEVICE)): the call
+    only enqueues.  Returns per-callback times: GPU timeline of the root stream and host clock."""
+    gas, torch, synth = env["gas"], env["torch"], env["synth"]
+    args, kind, chain, frames, ring, hrir = env["args"], env["kind"], env["chain"], env["frames"], env["ring"], env["hrir"]
+    K = gas.capi
+    G = len(devices)
+    multi = K.MultiContext(devices, max_sources=n_per_shard, frames=frames, er_ring_frames=ring, flags=K.FLAG_PEAKS_DRAINING_ONLY)
+    try:
+        prng = np.random.default_rng(4321)
+        slots, srcs, peaks, psets = [], [], [], []
+        for g, ctx in enumerate(multi.shards):
+            if hrir is not None:
+                ctx.hrtf_load(hrir)
+            sl = ctx.source_alloc_many(n_per_shard, kind, chain)
+            slots.append(np.ascontiguousarray(sl, np.uint32))
+            ctx.params_publish_batch(sl, synth.draw_params(prng, n_per_shard, dirs=args.dirs, ring_frames=max(ring, 2 * frames), frames=frames))
+            dev = f"cuda:{devices[g]}"
+            n_bufs = max(2, min(8, -(-(N_SRC_BUFFERS_BYTES // G) // (n_per_shard * frames * 8))))
+            srcs.append([torch.rand(n_per_shard, frames, 2, device=dev) - 0.5 for _ in range(n_bufs)])
+            peaks.append(torch.zeros(n_per_shard, 2, device=dev))
+            p = synth.draw_params(prng, n_per_shard, dirs=args.dirs, ring_frames=max(ring, 2 * frames), frames=frames)
+            psets.append(torch.from_numpy(p.view(np.uint8).reshape(n_per_shard, 128).copy()).to(dev))
+        out = torch.zeros(1, frames, 2, device=f"cuda:{devices[0]}")
+        torch.cuda.synchronize()
+        root = torch.cuda.ExternalStream(multi.lib.gas_multi_root_stream(multi.h), device=f"cuda:{devices[0]}")
+        # raw ctypes argument arrays built once: the loop below is the host side of a ~20 us callback
+        import ctypes as C
+
+        vp = C.c_void_p
+        a_sl = (vp * G)(*[s.ctypes.data for s in slots])
+        a_same = (vp * G)(*([None] * G))  # slots[g] == NULL: the shard's previous list (no re-grouping per callback)
+        a_pk = (vp * G)(*[t.data_ptr() for t in peaks])
+        a_n = (C.c_uint32 * G)(*([n_per_shard] * G))
+        a_src = [(vp * G)(*[srcs[g][b % len(srcs[g])].data_ptr() for g in range(G)]) for b in range(max(len(x) for x in srcs))]
+
+        def step(k):
+            if k % 2 == 0:  # the emulated physics tick: device-resident rows, per shard
+                for g, ctx in enumerate(multi.shards):
+                    ctx.params_publish_device(psets[g].data_ptr(), n_per_shard)
+            rc = multi.lib.gas_multi_process_block_mem(multi.h, a_src[k % len(a_src)], a_same, a_n, frames, vp(out.data_ptr()), a_pk, K.MEM_DEVICE)
+            if rc != 0:
+                raise RuntimeError(f"gas_multi_process_block_mem: {rc}")
+
+        rc = multi.lib.gas_multi_process_block_mem(multi.h, a_src[0], a_sl, a_n, frames, vp(out.data_ptr()), a_pk, K.MEM_DEVICE)  # names the lists
+        if rc != 0:
+            raise RuntimeError(f"gas_multi_process_block_mem: {rc}")
+        for k in range(warmup):
+            step(k)
+        multi.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        e0.record(root)
+        for k in range(callbacks):
+            step(k)
+        t_enq = time.perf_counter() - t0
+        e1.record(root)
+        multi.synchronize()
+        wall = time.perf_counter() - t0
+        gpu_ms = e0.elapsed_time(e1)
+        return {"shards": G, "devices": list(devices), "sources_per_shard": n_per_shard, "callbacks": callbacks, "ms_per_step": gpu_ms / callbacks, "wall_ms_per_step": wall * 1e3 / callbacks, "host_enqueue_us_per_step": t_enq * 1e6 / callbacks, "value": G * n_per_shard * frames * callbacks / (wall if len(set(devices)) > 1 else gpu_ms * 1e-3), "direct_write": os.environ.get("GAS_MULTI_DIRECT", "1") != "0"}
+    finally:
+        multi.close()
+
+
 def main():
     if len(sys.argv) >= 4 and sys.argv[1] == "--cpu-worker":  # child of cpu_baseline(): CPU only, prints seconds
         kind, chain, frames, dirs, hp, ring, n, blocks = json.loads(sys.argv[2])
@@ -403,6 +470,7 @@ def main():
     ap.add_argument("--xcd-directions", action="store_true", help="experiment: draw each source's HRIR direction from the eighth of the table that belongs to its workgroup's XCD (upper bound of an XCD-aware source partition)")
     ap.add_argument("--draining-every", type=int, default=64, help="1 source in N has ended its stream (exact peak needed, audio_spatializer.cpp:464-469); 0 = none")
     ap.add_argument("--exact-peaks", action="store_true", help="headline with the exact peak of every source")
+    ap.add_argument("--in-process", action="store_true", help="ONE process drives --gpus N devices through gas_multi_* (all-to-one peer writes of the 4 KiB partial mixes, one ordered sum on device 0, every callback: the real-time arrangement); launch WITHOUT torchrun.  With fewer visible GPUs than N the shards share the devices there are (one GPU: the per-callback cost of the gather + root sum)")
     args = ap.parse_args()
 
     import torch
@@ -414,6 +482,10 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.in_process:
+        if world != 1:
+            raise SystemExit("--in-process is a single process: launch it without torch.distributed.run")
+        return main_in_process(args, gas, torch, sharding, synth)
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
@@ -610,6 +682,13 @@ def main():
                 result["streams"] = {"ms_per_step": s_ms, "value": n_local * frames / (s_ms * 1e-3), "callbacks": n_cb, "what": "gas_process_block_streams: the same sources as 16-bit mono PCM streams resident in HBM (sampling fused into the HRTF launch; ordered mode, one k_mix_reduce per callback; GPU timeline)", "stream_bytes_per_callback": n_local * frames * 2}
                 sctx.close()
                 del sctx, pcm
+            if args.workload == "hrtf" and n_local == 8192:
+                # SURVEY 8e, real-time arrangement inside one process: the callback's sources split over G contexts of THIS
+                # device (what there is to measure on one GPU: the cost of the all-to-one gather + root sum per callback,
+                # beside the unsharded ordered callback above)
+                result["in_process_multi"] = {"what": "gas_multi_process_block_mem(GAS_MEM_DEVICE), G contexts sharing cuda:0, 8192 sources in total, a device-resident publish every 2nd callback, every callback gathered and summed on the root (no bucket); compare with ordered.ms_per_step (one context, same sources)", "runs": [in_process_multi(env, [local_rank] * G, n_local // G, callbacks=200) for G in (2, 8)]}
+                for r_ in result["in_process_multi"]["runs"]:
+                    r_["added_us_vs_one_context"] = (r_["ms_per_step"] - result["ordered"]["ms_per_step"]) * 1e3
         except Exception as e:  # the extras must never cost the headline line
             result["extras_error"] = repr(e)
     env["srcs"].clear()
@@ -630,6 +709,51 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def main_in_process(args, gas, torch, sharding, synth):
+    """bench.py --gpus N --in-process: the same workload, source-sharded over N contexts of ONE process (gas_multi_*)."""
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the spatializer has no CPU path")
+    kind, chain, frames, n_default, ring, desc = WORKLOADS[args.workload]
+    n_local = args.sources_per_gpu or n_default
+    visible = torch.cuda.device_count()
+    devices = [g % visible for g in range(args.gpus)]
+    rng = np.random.default_rng(1234)
+    hrir = synth.synthetic_hrir(rng, dirs=args.dirs) if 3 in chain else None
+    env = {"gas": gas, "torch": torch, "synth": synth, "sharding": sharding, "args": args, "kind": kind, "chain": chain, "frames": frames, "ring": ring, "hrir": hrir}
+    shared = len(set(devices)) < len(devices)
+    r = in_process_multi(env, devices, n_local, callbacks=args.steps, warmup=max(args.warmup, 30))
+    ms = r["wall_ms_per_step"] if not shared and len(devices) > 1 else r["ms_per_step"]
+    result = {
+        "metric": "mixed AudioFrames/s",
+        "value": args.gpus * n_local * frames / (ms * 1e-3),
+        "unit": "AudioFrames/s",
+        "n_gpus": len(set(devices)),
+        "steps": args.steps,
+        "warmup": max(args.warmup, 30),
+        "ms_per_step": ms,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {
+            "workload": desc,
+            "mode": "in-process (gas_multi_*): one context per shard, ordered callbacks, every shard's partial mix written all-to-one into the root's gather buffer and summed there EVERY callback (real-time arrangement, no reduce bucket)",
+            "timing": "host clock around the callbacks incl. the closing gas_multi_synchronize (several devices), or the root stream's GPU timeline (shards sharing one device)",
+            "shards": args.gpus,
+            "devices": devices,
+            "shards_share_devices": shared,
+            "sources_total": args.gpus * n_local,
+            "sources_per_shard": n_local,
+            "frames_per_callback": frames,
+            "parallelism": f"source-sharded x{args.gpus} in one process over devices {devices}",
+            "lib_sha16": lib_sha16(),
+        },
+        "in_process_multi": r,
+    }
+    print(json.dumps(result), flush=True)
 
 
 def probe_max_sources(gas, synth, torch, kind, chain, frames, hrir, dirs, samples=100):

@@ -166,6 +166,7 @@ EXPORTS = [
     "gas_fx_settings_publish",
     "gas_params_publish_batch",
     "gas_hrtf_load",
+    "gas_hrtf_load_positions",
     "gas_calc_spatialization",
     "gas_calc_spatialization_areas",
     "gas_stream_create",
@@ -245,6 +246,7 @@ def load_library():
     L.gas_fx_settings_publish.argtypes = [vp, vp, vp, u32]
     L.gas_params_publish_batch.argtypes = [vp, vp, vp, u32, i32]
     L.gas_hrtf_load.argtypes = [vp, vp, u32, u32]
+    L.gas_hrtf_load_positions.argtypes = [vp, vp, vp, u32, u32, u32, u32, i32, vp]
     L.gas_stream_create.argtypes = [vp, vp, i32, u32, C.c_uint64, C.POINTER(u32)]
     L.gas_stream_destroy.argtypes = [vp, u32]
     L.gas_stream_positions.argtypes = [vp, u32, vp]

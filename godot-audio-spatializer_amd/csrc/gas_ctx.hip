@@ -2413,9 +2413,10 @@ int gas_process_block_buses(gas_ctx *c, const gas_audio_frame *src, const uint32
 			all_plain_hrtf = c->slots[slots[i]].group == G_FX_HRTF;
 		}
 	}
-	const bool fused_hrtf = !all_mix && all_plain_hrtf && C == 1 && n_buses <= 2 && uni_ok(c) && !c->fused_streams && gas_hrtf_uni_waves() == 8;
+	// (three to six buses: one fused launch per pair of buses, the state committed by the last)
+	const bool fused_hrtf = !all_mix && all_plain_hrtf && C == 1 && uni_ok(c) && !c->fused_streams && gas_hrtf_uni_waves() == 8;
 	const bool staged = !all_mix && all_fx && C == 1 && !fused_hrtf;
-	if (reuse && (staged || (n_buses > 2 && all_fx))) {
+	if (reuse && staged) {
 		return fail(GAS_ERR_INVALID_ARGUMENT); // the staged form regroups: it needs the list
 	}
 	if (!reuse) {
@@ -2466,7 +2467,7 @@ int gas_process_block_buses(gas_ctx *c, const gas_audio_frame *src, const uint32
 			GAS_HIP(c, hipStreamSynchronize(c->stream)); // the pinned mirror is rewritten by the next snapshot
 		}
 		const uint32_t P = n ? (fused_hrtf ? gas_hrtf_uni_partials(n) : gas_biquad_partials(n)) : 0;
-		const size_t need = (size_t)(fused_hrtf && n_buses < 2 ? 2 : n_buses) * C * (P ? P : 1) * F * 2; // the fused [HRTF] form always writes two planes
+		const size_t need = (size_t)(fused_hrtf ? 2 * ((n_buses + 1) / 2) : n_buses) * C * (P ? P : 1) * F * 2; // the fused [HRTF] form writes two planes per launch
 		if (need > c->bus_partial_floats) {
 			GAS_HIP(c, hipStreamSynchronize(c->stream));
 			(void)hipFree(c->d_bus_partials);
@@ -2510,8 +2511,11 @@ int gas_process_block_buses(gas_ctx *c, const gas_audio_frame *src, const uint32
 				ga.slots = nullptr;
 				ga.slot_base = gr.slot_base;
 			}
-			// bus b's partial rows: [b * P, (b + 1) * P)
-			GAS_HIP(c, gas_launch_hrtf_uni(c->stream, ga, c->uni_peak_any && !c->uni_peak_all ? c->d_peak_bits : nullptr, c->uni_peak_all, c->st, c->tab, c->d_tw, F, c->hist_len, c->d_bus_partials, 0, nullptr, c->d_fade_env, nullptr, gas_deferred_reduce(), c->d_routes, P));
+			// bus b's partial rows: [b * P, (b + 1) * P); one launch per pair of buses, the last one commits the state
+			const uint32_t passes = (n_buses + 1) / 2;
+			for (uint32_t pass = 0; pass < passes; pass++) {
+				GAS_HIP(c, gas_launch_hrtf_uni(c->stream, ga, c->uni_peak_any && !c->uni_peak_all ? c->d_peak_bits : nullptr, c->uni_peak_all, c->st, c->tab, c->d_tw, F, c->hist_len, c->d_bus_partials, 2 * pass * P, nullptr, c->d_fade_env, nullptr, gas_deferred_reduce(), c->d_routes, P, 2 * pass, pass + 1 == passes));
+			}
 		} else if (staged) {
 			// effect kinds: the stages of every chain with rows out, then k_rows_accumulate_buses and one reduce over the
 			// buses (run_groups' staged-chain path, told about the buses)

@@ -76,8 +76,11 @@ struct UniLds {
 // bus b with weight w_b = (dry_bus == b) + (send_bus == b ? send : 0) per ear.  Bus 0 keeps the register sums (weighted),
 // bus 1's sums live in LDS (64 KB the plain form does not use) and are only touched by sources that reach it; the
 // epilogue runs once per bus.  Partial rows of bus b: [b * bus_rows + p_offset + workgroup].
+// More than two buses (a playback reaches up to six, audio_spatializer.cpp:283-287): one launch per PAIR of buses --
+// bus_base names the pair (buses bus_base, bus_base + 1) and only the last launch commits the per-source state (history
+// row, previous gain, peak), so every pass transforms the same windows.
 template <int SQ, bool SRC_PCM, bool BUS2, int UW>
-__global__ __launch_bounds__(UW * 64, UW > 8 ? 3 : GAS_HRTF_WAVES_PER_SIMD) void k_hrtf_uni(gas_group_args g, const uint32_t *__restrict__ peak_bits, uint32_t peak_all, gas_dev_state st, gas_hrtf_table tab, const float2 *__restrict__ tw, float *__restrict__ partials, uint32_t p_offset, gas_cursor *__restrict__ cursors, const float *__restrict__ fade_env, const gas_params *__restrict__ fresh, gas_deferred_reduce job, const gas_bus_route *__restrict__ routes, uint32_t bus_rows) {
+__global__ __launch_bounds__(UW * 64, UW > 8 ? 3 : GAS_HRTF_WAVES_PER_SIMD) void k_hrtf_uni(gas_group_args g, const uint32_t *__restrict__ peak_bits, uint32_t peak_all, gas_dev_state st, gas_hrtf_table tab, const float2 *__restrict__ tw, float *__restrict__ partials, uint32_t p_offset, gas_cursor *__restrict__ cursors, const float *__restrict__ fade_env, const gas_params *__restrict__ fresh, gas_deferred_reduce job, const gas_bus_route *__restrict__ routes, uint32_t bus_rows, uint32_t bus_base, uint32_t commit) {
 	constexpr bool LEAN = UniCfg<UW>::LEAN;
 	constexpr int UNI_SLICES = UniCfg<UW>::SLICES;
 	static_assert(!LEAN || (!SRC_PCM && !BUS2), "the twelve-wave form exists for float rows on one bus");
@@ -138,10 +141,10 @@ __global__ __launch_bounds__(UW * 64, UW > 8 ? 3 : GAS_HRTF_WAVES_PER_SIMD) void
 	if constexpr (BUS2) {
 		if (have) {
 			const gas_bus_route r = routes[lm.slot];
-			my_w0l = gas_bus_weight(r, 0u, 0, 0);
-			my_w0r = gas_bus_weight(r, 0u, 0, 1);
-			my_w1l = gas_bus_weight(r, 1u, 0, 0);
-			my_w1r = gas_bus_weight(r, 1u, 0, 1);
+			my_w0l = gas_bus_weight(r, bus_base, 0, 0);
+			my_w0r = gas_bus_weight(r, bus_base, 0, 1);
+			my_w1l = gas_bus_weight(r, bus_base + 1u, 0, 0);
+			my_w1r = gas_bus_weight(r, bus_base + 1u, 0, 1);
 		}
 #pragma unroll
 		for (int j = 0; j < 8; j++) {
@@ -162,6 +165,9 @@ __global__ __launch_bounds__(UW * 64, UW > 8 ? 3 : GAS_HRTF_WAVES_PER_SIMD) void
 		}
 		const uint32_t e = my_entry;
 		my_flag = peak_all ? 1u : (peak_bits ? (peak_bits[e >> 5] >> (e & 31)) & 1u : 0u);
+		if (BUS2 && !commit) {
+			my_flag = 0; // the peak (of y, before any bus factor) is the committing pass's
+		}
 	}
 	if constexpr (SRC_PCM) {
 		if (first < last) {
@@ -377,7 +383,9 @@ __global__ __launch_bounds__(UW * 64, UW > 8 ? 3 : GAS_HRTF_WAVES_PER_SIMD) void
 			GAS_UNI_STAMP(2);
 		}
 #endif
-		store_history<HQ>(st.hrtf_hist + (size_t)m.slot * HL, lane, &xq[FQ]); // new history = x_full[F .. F + HL)
+		if (!BUS2 || commit) { // wave-uniform; a non-committing bus pass leaves the state for the next pass to read
+			store_history<HQ>(st.hrtf_hist + (size_t)m.slot * HL, lane, &xq[FQ]); // new history = x_full[F .. F + HL)
+		}
 		if constexpr (SRC_PCM) {
 			if (lane == 0 && m.hf) { // advance the playback cursor (audio_spatializer.cpp:378,398)
 				cursors[m.slot].pos = m.pos + m.mixed;
@@ -423,7 +431,7 @@ __global__ __launch_bounds__(UW * 64, UW > 8 ? 3 : GAS_HRTF_WAVES_PER_SIMD) void
 	GAS_UNI_STAMP(3);
 
 	// ---- behind the loop: what nobody waits for ------------------------------------------------------------------
-	if (have) {
+	if (have && (!BUS2 || commit)) {
 		st.hrtf_prev_gain[lm.slot] = lm.g1;
 		if (!my_flag) { // "not measured": never passes the gate (audio_spatializer.cpp:464-469)
 			*reinterpret_cast<float2 *>(g.peaks + (size_t)lm.row * 2) = make_float2(__builtin_inff(), __builtin_inff());
@@ -571,7 +579,7 @@ bool gas_hrtf_uni_twelve(uint32_t n, bool streams, bool buses) {
 	return !streams && !buses && mn != 0 && n >= mn && n >= wgs * UNI_W12 && n <= wgs * UNI_W12 * 64;
 }
 
-hipError_t gas_launch_hrtf_uni(hipStream_t stream, const gas_group_args &g, const uint32_t *peak_bits, bool peak_all, const gas_dev_state &st, const gas_hrtf_table &tab, const float2 *twiddles, uint32_t frames, uint32_t hist_len, float *partials, uint32_t p_offset, gas_cursor *cursors, const float *fade_env, const gas_params *fresh, const gas_deferred_reduce &job, const gas_bus_route *routes, uint32_t bus_rows) {
+hipError_t gas_launch_hrtf_uni(hipStream_t stream, const gas_group_args &g, const uint32_t *peak_bits, bool peak_all, const gas_dev_state &st, const gas_hrtf_table &tab, const float2 *twiddles, uint32_t frames, uint32_t hist_len, float *partials, uint32_t p_offset, gas_cursor *cursors, const float *fade_env, const gas_params *fresh, const gas_deferred_reduce &job, const gas_bus_route *routes, uint32_t bus_rows, uint32_t bus_base, bool commit) {
 	if (g.n == 0) {
 		return hipSuccess;
 	}
@@ -582,7 +590,7 @@ hipError_t gas_launch_hrtf_uni(hipStream_t stream, const gas_group_args &g, cons
 	const uint32_t all = peak_all ? 1u : 0u;
 	const bool twelve = gas_hrtf_uni_twelve(g.n, cursors != nullptr, routes != nullptr);
 	const dim3 grid(wgs), block((twelve ? UNI_W12 : UNI_W) * 64);
-#define GAS_UNI_GO(SQv, PCM, BUS, W) hipLaunchKernelGGL((k_hrtf_uni<SQv, PCM, BUS, W>), grid, block, 0, stream, g, peak_bits, all, st, tab, twiddles, partials, p_offset, cursors, fade_env, fresh, job, routes, bus_rows)
+#define GAS_UNI_GO(SQv, PCM, BUS, W) hipLaunchKernelGGL((k_hrtf_uni<SQv, PCM, BUS, W>), grid, block, 0, stream, g, peak_bits, all, st, tab, twiddles, partials, p_offset, cursors, fade_env, fresh, job, routes, bus_rows, bus_base, commit ? 1u : 0u)
 #define GAS_UNI_CASE(SQv)                      \
 	case SQv:                                  \
 		if (routes) {                          \

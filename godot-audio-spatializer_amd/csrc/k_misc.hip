@@ -509,7 +509,8 @@ namespace {
 // Measured HRIR sets come as M irregular (azimuth, elevation) positions; the library indexes directions on an
 // azimuth x elevation grid (cell = elevation_index * az_steps + azimuth_index, the arithmetic of
 // k_calc_spatialization).  One workgroup per grid cell: every thread scans a strided share of the positions keeping its
-// three nearest (largest dot product with the cell's unit vector, ties to the smaller index), LDS-merges them into the
+// three nearest (smallest chord |cell - position| on the unit sphere, ties to the smaller index: the chord, unlike the
+// dot product, still resolves neighbours a fraction of a degree apart in f32), LDS-merges them into the
 // workgroup's three nearest, then writes the cell's HRIR pair: the nearest one (interpolation 0) or the blend of the
 // three weighted by 1 / angle (1).  NEW (AudioSpatializerHRTF, no reference counterpart): parity unpinned.
 struct Near3 {
@@ -518,18 +519,18 @@ struct Near3 {
 };
 
 __device__ __forceinline__ void near3_insert(Near3 &n, float d, uint32_t i) {
-	// keep (dot descending, index ascending)
-	if (d > n.d[2] || (d == n.d[2] && i < n.i[2])) {
+	// keep (squared chord ascending, index ascending)
+	if (d < n.d[2] || (d == n.d[2] && i < n.i[2])) {
 		n.d[2] = d;
 		n.i[2] = i;
-		if (n.d[2] > n.d[1] || (n.d[2] == n.d[1] && n.i[2] < n.i[1])) {
+		if (n.d[2] < n.d[1] || (n.d[2] == n.d[1] && n.i[2] < n.i[1])) {
 			const float td = n.d[1];
 			const uint32_t ti = n.i[1];
 			n.d[1] = n.d[2];
 			n.i[1] = n.i[2];
 			n.d[2] = td;
 			n.i[2] = ti;
-			if (n.d[1] > n.d[0] || (n.d[1] == n.d[0] && n.i[1] < n.i[0])) {
+			if (n.d[1] < n.d[0] || (n.d[1] == n.d[0] && n.i[1] < n.i[0])) {
 				const float ud = n.d[0];
 				const uint32_t ui = n.i[0];
 				n.d[0] = n.d[1];
@@ -554,11 +555,11 @@ __global__ __launch_bounds__(REGRID_THREADS) void k_hrtf_regrid(const float *__r
 	const float el = el_steps > 1 ? -1.57079632679489661923f + (float)ei * (3.14159265358979323846f / (float)(el_steps - 1)) : 0.0f;
 	// unit vector, azimuth from -Z towards +X, elevation from the XZ plane (audio_spatializer_hrtf.cpp fill_pod)
 	const float cx = cosf(el) * sinf(az), cy = sinf(el), cz = -cosf(el) * cosf(az);
-	Near3 n{ { -2.0f, -2.0f, -2.0f }, { 0xffffffffu, 0xffffffffu, 0xffffffffu } };
+	Near3 n{ { 8.0f, 8.0f, 8.0f }, { 0xffffffffu, 0xffffffffu, 0xffffffffu } };
 	for (uint32_t k = threadIdx.x; k < m; k += REGRID_THREADS) {
 		const float paz = positions[2 * k], pel = positions[2 * k + 1];
-		const float px = cosf(pel) * sinf(paz), py = sinf(pel), pz = -cosf(pel) * cosf(paz);
-		near3_insert(n, (cx * px + cy * py) + cz * pz, k);
+		const float dx = cosf(pel) * sinf(paz) - cx, dy = sinf(pel) - cy, dz = -cosf(pel) * cosf(paz) - cz;
+		near3_insert(n, (dx * dx + dy * dy) + dz * dz, k);
 	}
 	for (int j = 0; j < 3; j++) {
 		sd[threadIdx.x * 3 + j] = n.d[j];
@@ -566,7 +567,7 @@ __global__ __launch_bounds__(REGRID_THREADS) void k_hrtf_regrid(const float *__r
 	}
 	__syncthreads();
 	if (threadIdx.x == 0) { // 768 candidates: a serial merge in the same (dot, index) order, deterministic
-		Near3 g{ { -2.0f, -2.0f, -2.0f }, { 0xffffffffu, 0xffffffffu, 0xffffffffu } };
+		Near3 g{ { 8.0f, 8.0f, 8.0f }, { 0xffffffffu, 0xffffffffu, 0xffffffffu } };
 		for (int t = 0; t < REGRID_THREADS * 3; t++) {
 			if (si[t] != 0xffffffffu) {
 				near3_insert(g, sd[t], si[t]);
@@ -576,8 +577,8 @@ __global__ __launch_bounds__(REGRID_THREADS) void k_hrtf_regrid(const float *__r
 		if (interpolation != 0 && g.i[1] != 0xffffffffu) {
 			float sum = 0.0f;
 			for (int j = 0; j < 3; j++) {
-				const float dot = fminf(1.0f, fmaxf(-1.0f, g.d[j]));
-				w[j] = g.i[j] != 0xffffffffu ? 1.0f / (acosf(dot) + 1e-4f) : 0.0f;
+				const float angle = 2.0f * asinf(fminf(1.0f, 0.5f * sqrtf(g.d[j]))); // chord = 2 sin(angle / 2)
+				w[j] = g.i[j] != 0xffffffffu ? 1.0f / (angle + 1e-4f) : 0.0f;
 				sum += w[j];
 			}
 			for (int j = 0; j < 3; j++) {

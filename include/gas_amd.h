@@ -302,9 +302,10 @@ int gas_bus_routes_publish(gas_ctx *ctx, const uint32_t *slots, const gas_bus_ro
 /* gas_process_block with out = [n_buses][C][frames] (1 <= n_buses <= GAS_MAX_BUSES).  Either every source is
  * GAS_KIND_3D_MIX (the mix-channel buses, fused into the biquad launch), or every source is a non-empty effect chain
  * on a one-pair context (the chains run staged -- per-source rows -- and the rows are mixed per bus with send[0]);
- * anything else is GAS_ERR_UNSUPPORTED_CHAIN.  [HRTF] sources onto one or two buses run fused (the second bus's sums in
- * LDS).  slots == NULL reuses the previous call's list (3D mix and fused [HRTF] forms).  Peaks are those of y (before any bus factor), as the reference's gate
- * sees them (audio_spatializer.cpp:436-443). */
+ * anything else is GAS_ERR_UNSUPPORTED_CHAIN.  Plain [HRTF] sources run fused, one launch per PAIR of buses (the second
+ * bus's spectra sums in LDS), the last launch committing the playbacks' state.  slots == NULL reuses the previous call's
+ * list (3D mix and fused [HRTF] forms).  Peaks are those of y (before any bus factor), as the reference's gate sees them
+ * (audio_spatializer.cpp:436-443). */
 int gas_process_block_buses(gas_ctx *ctx, const gas_audio_frame *src, const uint32_t *slots, uint32_t n, uint32_t frames, gas_audio_frame *out, uint32_t n_buses, float *peaks, int mem);
 
 /* ---- compatibility / parity path: the exact _process_frames and _mix_channel

@@ -221,7 +221,10 @@ def test_bus_call_reuses_the_list(gas):
         assert rc == 0
         ctx.synchronize()
         assert ctx.lib.gas_process_block_buses(ctx.h, src.data_ptr(), None, n + 1, F, out[0].data_ptr(), 2, pk.data_ptr(), K.MEM_DEVICE) != 0
-        assert ctx.lib.gas_process_block_buses(ctx.h, src.data_ptr(), None, n, F, out[0].data_ptr(), 3, pk.data_ptr(), K.MEM_DEVICE) != 0  # three buses: staged, needs the list
+        out3 = torch.zeros(3, 1, F, 2, device="cuda")
+        assert ctx.lib.gas_process_block_buses(ctx.h, src.data_ptr(), None, n, F, out3.data_ptr(), 3, pk.data_ptr(), K.MEM_DEVICE) == 0  # three buses: two fused launches over the same list
+        ctx.synchronize()
+        assert not out3[2].any()  # nobody sends to bus 2
     with gas.SpatializerContext(max_sources=n, frames=F) as ctx2:
         ctx2.hrtf_load(hrir)
         slots2 = ctx2.source_alloc_many(n, K.KIND_EFFECT, (K.FX_HRTF,))
@@ -231,9 +234,12 @@ def test_bus_call_reuses_the_list(gas):
         s2 = np.ascontiguousarray(slots2, np.uint32)
         for _ in range(2):
             assert ctx2.lib.gas_process_block_buses(ctx2.h, src.data_ptr(), s2.ctypes.data, n, F, out[1].data_ptr(), 2, pk.data_ptr(), K.MEM_DEVICE) == 0
+        out3b = torch.zeros(3, 1, F, 2, device="cuda")
+        assert ctx2.lib.gas_process_block_buses(ctx2.h, src.data_ptr(), s2.ctypes.data, n, F, out3b.data_ptr(), 3, pk.data_ptr(), K.MEM_DEVICE) == 0
         ctx2.synchronize()
     a, b = out[0].cpu().numpy(), out[1].cpu().numpy()
     assert np.array_equal(a, b) and np.abs(a[1]).max() > 0
+    assert np.array_equal(out3.cpu().numpy(), out3b.cpu().numpy()) and np.abs(out3b[1].cpu().numpy()).max() > 0  # the third callback, reused list vs named list
 
 
 @pytest.mark.parametrize("peaks_mode", ["every_source", "draining_only"])

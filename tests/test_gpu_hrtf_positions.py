@@ -24,15 +24,15 @@ def regrid_ref(pos, hrir, n_az, n_el, interpolation):
         for ai in range(n_az):
             az = ai * 2 * np.pi / n_az
             el = -np.pi / 2 + ei * np.pi / (n_el - 1) if n_el > 1 else 0.0
-            d = p @ unit(np.float64(az), np.float64(el))
-            order = np.lexsort((np.arange(m), -d))
+            d = np.sqrt(((p - unit(np.float64(az), np.float64(el))) ** 2).sum(-1))  # chord on the unit sphere
+            order = np.lexsort((np.arange(m), d))
             k = 1 if interpolation == 0 else min(3, m)
-            if m > k and d[order[k - 1]] - d[order[k]] < 1e-5:
+            if m > k and d[order[k]] - d[order[k - 1]] < 1e-5:
                 safe[ei * n_az + ai] = False  # the k-th and (k+1)-th nearest are a near-tie
             if interpolation == 0 or m == 1:
                 out[ei * n_az + ai, :, :taps] = hrir[order[0]]
             else:
-                w = 1.0 / (np.arccos(np.clip(d[order[:k]], -1, 1)) + 1e-4)
+                w = 1.0 / (2 * np.arcsin(np.minimum(1.0, d[order[:k]] / 2)) + 1e-4)
                 w /= w.sum()
                 out[ei * n_az + ai, :, :taps] = np.tensordot(w, hrir[order[:k]].astype(np.float64), 1)
     return out, safe

@@ -107,20 +107,27 @@ def _run_multi(gas, ob, devices, device_memory):
     return got, want
 
 
-def test_multi_device_memory_entry_on_one_gpu(gas, ob):
+@pytest.mark.parametrize("direct", ["1", "0"])
+def test_multi_device_memory_entry_on_one_gpu(gas, ob, direct, monkeypatch):
     """gas_multi_process_block_mem(GAS_MEM_DEVICE): no staging, no host wait, gather buffer reuse guarded by the root's
-    event -- five queued callbacks over three shards of the one GPU equal the single-context mixes."""
+    event -- five queued callbacks over three shards of the one GPU equal the single-context mixes.  direct = 1: every
+    shard's own final sum writes its row of the root's gather buffer (SURVEY 8e's all-to-one direct write); 0: the
+    hipMemcpyPeerAsync form."""
+    monkeypatch.setenv("GAS_MULTI_DIRECT", direct)
     got, want = _run_multi(gas, ob, [0, 0, 0], device_memory=True)
     for g, w in zip(got, want):
         assert rel_rms(g[0], w[0]) <= TOL
 
 
+@pytest.mark.parametrize("direct", ["1", "0"])
 @pytest.mark.parametrize("device_memory", [False, True])
-def test_multi_over_two_real_gpus(gas, ob, device_memory):
-    """The real peer path (hipMemcpyPeerAsync into the root's gather buffer over xGMI): needs two GPUs, skipped on the
-    one-GPU boxes this repository is developed on -- so that the first multi-GPU run is not the first execution."""
+def test_multi_over_two_real_gpus(gas, ob, device_memory, direct, monkeypatch):
+    """The real peer path (peer stores / hipMemcpyPeerAsync into the root's gather buffer over xGMI): needs two GPUs,
+    skipped on the one-GPU boxes this repository is developed on -- so that the first multi-GPU run is not the first
+    execution."""
     if _n_gpus() < 2:
         pytest.skip("needs >= 2 GPUs")
+    monkeypatch.setenv("GAS_MULTI_DIRECT", direct)
     got, want = _run_multi(gas, ob, [0, 1], device_memory=device_memory)
     for g, w in zip(got, want):
         assert rel_rms(g[0], w[0]) <= TOL
