@@ -153,6 +153,10 @@ typedef struct gas_config {
  *  - `src`, `peaks` and device-published parameter rows of a call must stay valid and unmodified until `depth - 1`
  *    further gas_process_block calls on this context (or gas_ctx_join_outputs / gas_ctx_synchronize) have returned;
  *  - `out` is complete only after gas_ctx_join_outputs / gas_ctx_synchronize (or any ordered call), in stream order;
+ *  - every call waiting for its batch or its deferred sum needs ITS OWN `out` (and `peaks`) buffer: the sums of the
+ *    queued callbacks are written out of call order (a block's sum rides in a later launch, the join sums everything
+ *    pending in one parallel launch), so two queued calls that share an `out` race; the unbatched mode's
+ *    "last call wins" does not hold here;
  *  - every entry of the context must be called from ONE thread (the recorded calls are run by whoever comes next:
  *    anything that changes what they must see -- a new list, host-published parameters, frees, any other entry that
  *    enqueues work -- first runs them, exactly as the unbatched mode would have);
