@@ -613,12 +613,19 @@ __device__ __forceinline__ void wave_range(uint32_t n, uint32_t gw, uint32_t n_w
 // History rows are stored lane-major -- element lane * HQ + q holds x[lane + 64 q] -- so a lane's HQ samples are one
 // contiguous 4*HQ-byte piece (one 16-byte access at F = 512 instead of four 4-byte ones: the history cost 3.1 us of
 // the 16.7 us kernel as 4-byte accesses).  The layout is private to this file; k_zero_slot only writes zeros.
+#ifndef GAS_NT_HIST
+#define GAS_NT_HIST 0 // EXPERIMENT: history rows (read once, written once per callback) with non-temporal accesses too
+#endif
 template <int HQ>
 __device__ __forceinline__ void load_history(const float *__restrict__ row, int lane, float (&h)[HQ]) {
 	if constexpr (HQ % 4 == 0) {
 #pragma unroll
 		for (int q = 0; q < HQ; q += 4) {
+#if GAS_NT_HIST
+			const gas_v4f v = __builtin_nontemporal_load(reinterpret_cast<const gas_v4f *>(row + lane * HQ + q));
+#else
 			const float4 v = *reinterpret_cast<const float4 *>(row + lane * HQ + q);
+#endif
 			h[q] = v.x; h[q + 1] = v.y; h[q + 2] = v.z; h[q + 3] = v.w;
 		}
 	} else if constexpr (HQ % 2 == 0) {
@@ -640,7 +647,12 @@ __device__ __forceinline__ void store_history(float *__restrict__ row, int lane,
 	if constexpr (HQ % 4 == 0) {
 #pragma unroll
 		for (int q = 0; q < HQ; q += 4) {
+#if GAS_NT_HIST
+			const gas_v4f v = { h[q], h[q + 1], h[q + 2], h[q + 3] };
+			__builtin_nontemporal_store(v, reinterpret_cast<gas_v4f *>(row + lane * HQ + q));
+#else
 			*reinterpret_cast<float4 *>(row + lane * HQ + q) = make_float4(h[q], h[q + 1], h[q + 2], h[q + 3]);
+#endif
 		}
 	} else if constexpr (HQ % 2 == 0) {
 #pragma unroll

@@ -341,3 +341,32 @@ def test_up_to_six_buses_per_playback(gas, ob, kind_name, chain, channels):
             for b in range(n_buses):
                 for c in range(channels):
                     assert rel_rms(got[b, c], want[b, c]) <= TOL, (cb, b, c)
+
+
+def test_probe_between_bus_callbacks_leaves_the_bus_buffers_alone(gas, ob):
+    """Regression (round-2 advisor, high): gas_bandwidth_probe growing its arena used to free the bus form's route /
+    partial / output buffers; buses -> probe -> buses on ONE context must keep working and agree with a twin context
+    that never probed."""
+    from godot_audio_spatializer_amd import synth
+
+    K = gas.capi
+    n, F = 300, 512
+    outs = []
+    for probe in (True, False):
+        rng = np.random.default_rng(8)
+        with gas.SpatializerContext(max_sources=n, frames=F, channel_count=2) as ctx:
+            slots = ctx.source_alloc_many(n, K.KIND_3D_MIX)
+            routes = K.bus_routes(n)
+            routes["dry_bus"] = rng.integers(0, 3, n)
+            routes["send_bus"] = 2
+            routes["send"] = 0.5
+            ctx.bus_routes_publish(slots, routes)
+            got = []
+            for cb in range(3):
+                ctx.params_publish_batch(slots, synth.draw_params(rng, n, channel_count=2, frames=F))
+                got.append(ctx.process_block_buses(synth.draw_sources(rng, n, F), slots, 3)[0])
+                if probe and cb == 0:
+                    assert ctx.bandwidth_probe(8 << 20, 1 << 20, 256, 2, 3) > 0  # grows both arenas
+                    assert ctx.bandwidth_probe(32 << 20, 4 << 20, 256, 2, 3) > 0  # ... and again
+            outs.append(np.stack(got))
+    np.testing.assert_array_equal(outs[0], outs[1])
