@@ -187,6 +187,7 @@ EXPORTS = [
     "gas_ctx_set_batch_depth",
     "gas_ctx_read_hrtf_order",
     "gas_tune_uni12_min",
+    "gas_tune_nt_hist_min",
 ]
 
 
@@ -267,6 +268,8 @@ def load_library():
     L.gas_ctx_read_hrtf_order.argtypes = [vp, vp, u32]
     L.gas_tune_uni12_min.argtypes = [u32]
     L.gas_tune_uni12_min.restype = u32
+    L.gas_tune_nt_hist_min.argtypes = [u32]
+    L.gas_tune_nt_hist_min.restype = u32
     L.gas_ctx_set_batch_depth.argtypes = [vp, u32]
     _lib = L
     return L

@@ -70,7 +70,7 @@ __device__ unsigned long long gas_stamps[8192 * GAS_STAMP_SLOTS];
 #else
 #define GAS_STAMP(i) do { } while (0)
 #endif
-#ifdef GAS_USE_NT // measured: no effect on MI355X for this kernel (profiles/r01_notes.md); kept as a switch
+#ifdef GAS_USE_NT // set by k_hrtf_multi.hip and (round 3) k_hrtf_uni.hip; k_hrtf_ols showed no effect in round 1 (profiles/r01_notes.md)
 #define GAS_NT_LOAD(p) __builtin_nontemporal_load(p)
 #define GAS_NT_STORE(v, p) __builtin_nontemporal_store(v, p)
 #else
@@ -613,19 +613,25 @@ __device__ __forceinline__ void wave_range(uint32_t n, uint32_t gw, uint32_t n_w
 // History rows are stored lane-major -- element lane * HQ + q holds x[lane + 64 q] -- so a lane's HQ samples are one
 // contiguous 4*HQ-byte piece (one 16-byte access at F = 512 instead of four 4-byte ones: the history cost 3.1 us of
 // the 16.7 us kernel as 4-byte accesses).  The layout is private to this file; k_zero_slot only writes zeros.
-#ifndef GAS_NT_HIST
-#define GAS_NT_HIST 0 // EXPERIMENT: history rows (read once, written once per callback) with non-temporal accesses too
-#endif
+// `nt` (wave-uniform): non-temporal accesses for rows in HBM that nothing re-reads before the caches have turned over --
+// callbacks whose history rows (1 KiB per source, read once and written once per callback) exceed what the Infinity
+// Cache keeps from one callback to the next.  Measured on the synchronous kernel (profiles/r03_notes.md section 3): with
+// the rows non-temporal 1 M sources take 1264 instead of 1350 us, 65 536 sources 82.6 instead of 80.8 us (there the row
+// written by callback t is still cached when callback t + 1 asks for it), so the caller decides by size.
 template <int HQ>
-__device__ __forceinline__ void load_history(const float *__restrict__ row, int lane, float (&h)[HQ]) {
+__device__ __forceinline__ void load_history(const float *__restrict__ row, int lane, float (&h)[HQ], bool nt = false) {
 	if constexpr (HQ % 4 == 0) {
+		if (nt) {
+#pragma unroll
+			for (int q = 0; q < HQ; q += 4) {
+				const gas_v4f v = __builtin_nontemporal_load(reinterpret_cast<const gas_v4f *>(row + lane * HQ + q));
+				h[q] = v.x; h[q + 1] = v.y; h[q + 2] = v.z; h[q + 3] = v.w;
+			}
+			return;
+		}
 #pragma unroll
 		for (int q = 0; q < HQ; q += 4) {
-#if GAS_NT_HIST
-			const gas_v4f v = __builtin_nontemporal_load(reinterpret_cast<const gas_v4f *>(row + lane * HQ + q));
-#else
 			const float4 v = *reinterpret_cast<const float4 *>(row + lane * HQ + q);
-#endif
 			h[q] = v.x; h[q + 1] = v.y; h[q + 2] = v.z; h[q + 3] = v.w;
 		}
 	} else if constexpr (HQ % 2 == 0) {
@@ -643,16 +649,19 @@ __device__ __forceinline__ void load_history(const float *__restrict__ row, int 
 }
 
 template <int HQ>
-__device__ __forceinline__ void store_history(float *__restrict__ row, int lane, const float *h) {
+__device__ __forceinline__ void store_history(float *__restrict__ row, int lane, const float *h, bool nt = false) {
 	if constexpr (HQ % 4 == 0) {
+		if (nt) {
+#pragma unroll
+			for (int q = 0; q < HQ; q += 4) {
+				const gas_v4f v = { h[q], h[q + 1], h[q + 2], h[q + 3] };
+				__builtin_nontemporal_store(v, reinterpret_cast<gas_v4f *>(row + lane * HQ + q));
+			}
+			return;
+		}
 #pragma unroll
 		for (int q = 0; q < HQ; q += 4) {
-#if GAS_NT_HIST
-			const gas_v4f v = { h[q], h[q + 1], h[q + 2], h[q + 3] };
-			__builtin_nontemporal_store(v, reinterpret_cast<gas_v4f *>(row + lane * HQ + q));
-#else
 			*reinterpret_cast<float4 *>(row + lane * HQ + q) = make_float4(h[q], h[q + 1], h[q + 2], h[q + 3]);
-#endif
 		}
 	} else if constexpr (HQ % 2 == 0) {
 #pragma unroll

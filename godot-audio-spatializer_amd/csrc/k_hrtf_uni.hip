@@ -27,6 +27,11 @@
 // per source = F*8 (frames) + 2*hist_len*4 (history r+w) + 24 (gain, direction, previous gain r/w, peak).
 #include <cstdlib>
 
+// Source rows are loaded non-temporal (round 3): once-touched frames that do not displace the HRIR rows -- the only
+// data of the launch that is re-read -- from the XCD's L2.  Measured, synchronous callback (profiles/r03_notes.md
+// section 3): 8192 sources 16.0 -> 14.5 us, 65 536 sources 89.6 -> 80.8 us, 1 M sources 1405 -> 1350 us.  (Round 1
+// found no effect on k_hrtf_ols, whose table was twice the size and whose launch was latency-bound elsewhere.)
+#define GAS_USE_NT 1
 #include "gas_hrtf_wave.h"
 
 #ifndef GAS_UNI12_DEFAULT_MIN
@@ -80,7 +85,7 @@ struct UniLds {
 // bus_base names the pair (buses bus_base, bus_base + 1) and only the last launch commits the per-source state (history
 // row, previous gain, peak), so every pass transforms the same windows.
 template <int SQ, bool SRC_PCM, bool BUS2, int UW>
-__global__ __launch_bounds__(UW * 64, UW > 8 ? 3 : GAS_HRTF_WAVES_PER_SIMD) void k_hrtf_uni(gas_group_args g, const uint32_t *__restrict__ peak_bits, uint32_t peak_all, gas_dev_state st, gas_hrtf_table tab, const float2 *__restrict__ tw, float *__restrict__ partials, uint32_t p_offset, gas_cursor *__restrict__ cursors, const float *__restrict__ fade_env, const gas_params *__restrict__ fresh, gas_deferred_reduce job, const gas_bus_route *__restrict__ routes, uint32_t bus_rows, uint32_t bus_base, uint32_t commit) {
+__global__ __launch_bounds__(UW * 64, UW > 8 ? 3 : GAS_HRTF_WAVES_PER_SIMD) void k_hrtf_uni(gas_group_args g, const uint32_t *__restrict__ peak_bits, uint32_t peak_all, gas_dev_state st, gas_hrtf_table tab, const float2 *__restrict__ tw, float *__restrict__ partials, uint32_t p_offset, gas_cursor *__restrict__ cursors, const float *__restrict__ fade_env, const gas_params *__restrict__ fresh, gas_deferred_reduce job, const gas_bus_route *__restrict__ routes, uint32_t bus_rows, uint32_t bus_base, uint32_t commit, uint32_t nt_hist) {
 	constexpr bool LEAN = UniCfg<UW>::LEAN;
 	constexpr int UNI_SLICES = UniCfg<UW>::SLICES;
 	static_assert(!LEAN || (!SRC_PCM && !BUS2), "the twelve-wave form exists for float rows on one bus");
@@ -131,7 +136,7 @@ __global__ __launch_bounds__(UW * 64, UW > 8 ? 3 : GAS_HRTF_WAVES_PER_SIMD) void
 		SrcMeta m0{};
 		m0.slot = (uint32_t)__builtin_amdgcn_readlane((int)lm.slot, 0);
 		m0.row = (uint32_t)__builtin_amdgcn_readlane((int)lm.row, 0);
-		load_history<HQ>(st.hrtf_hist + (size_t)m0.slot * HL, lane, rawh);
+		load_history<HQ>(st.hrtf_hist + (size_t)m0.slot * HL, lane, rawh, nt_hist != 0);
 		if constexpr (!SRC_PCM) {
 			load_window<false, FQ>(g, m0, lane, fade_env, raw);
 		}
@@ -384,7 +389,7 @@ __global__ __launch_bounds__(UW * 64, UW > 8 ? 3 : GAS_HRTF_WAVES_PER_SIMD) void
 		}
 #endif
 		if (!BUS2 || commit) { // wave-uniform; a non-committing bus pass leaves the state for the next pass to read
-			store_history<HQ>(st.hrtf_hist + (size_t)m.slot * HL, lane, &xq[FQ]); // new history = x_full[F .. F + HL)
+			store_history<HQ>(st.hrtf_hist + (size_t)m.slot * HL, lane, &xq[FQ], nt_hist != 0); // new history = x_full[F .. F + HL)
 		}
 		if constexpr (SRC_PCM) {
 			if (lane == 0 && m.hf) { // advance the playback cursor (audio_spatializer.cpp:378,398)
@@ -395,7 +400,7 @@ __global__ __launch_bounds__(UW * 64, UW > 8 ? 3 : GAS_HRTF_WAVES_PER_SIMD) void
 			}
 		}
 		if (has_next) {
-			load_history<HQ>(st.hrtf_hist + (size_t)mn.slot * HL, lane, rawh);
+			load_history<HQ>(st.hrtf_hist + (size_t)mn.slot * HL, lane, rawh, nt_hist != 0);
 			load_window<SRC_PCM, FQ>(g, mn, lane, fade_env, raw);
 		}
 		// z = a + i b : a = x_full[0..512), b = x_full[S..S+512) -- one complex FFT serves both sub-blocks
@@ -574,6 +579,24 @@ extern "C" uint32_t gas_tune_uni12_min(uint32_t min_sources) {
 	return was;
 }
 
+// From how many sources a callback's history rows (1 KiB each at F = 512, read and written once per callback) are
+// accessed non-temporal: when they no longer survive in the 256 MiB Infinity Cache from one callback to the next.
+// GAS_NT_HIST_MIN / gas_tune_nt_hist_min() override (measurement).
+static uint32_t g_nt_hist_min = [] {
+	const char *e = getenv("GAS_NT_HIST_MIN");
+	return e ? (uint32_t)strtoul(e, nullptr, 10) : 196608u;
+}();
+
+static uint32_t nt_hist_min_sources() {
+	return g_nt_hist_min;
+}
+
+extern "C" uint32_t gas_tune_nt_hist_min(uint32_t min_sources) {
+	const uint32_t was = g_nt_hist_min;
+	g_nt_hist_min = min_sources;
+	return was;
+}
+
 bool gas_hrtf_uni_twelve(uint32_t n, bool streams, bool buses) {
 	const uint32_t wgs = gas_hrtf_uni_partials(n), mn = uni12_min_sources();
 	return !streams && !buses && mn != 0 && n >= mn && n >= wgs * UNI_W12 && n <= wgs * UNI_W12 * 64;
@@ -589,8 +612,9 @@ hipError_t gas_launch_hrtf_uni(hipStream_t stream, const gas_group_args &g, cons
 	const uint32_t wgs = gas_hrtf_uni_partials(g.n);
 	const uint32_t all = peak_all ? 1u : 0u;
 	const bool twelve = gas_hrtf_uni_twelve(g.n, cursors != nullptr, routes != nullptr);
+	const uint32_t nt_hist = g.n >= nt_hist_min_sources() ? 1u : 0u; // history rows larger than what stays cached between callbacks
 	const dim3 grid(wgs), block((twelve ? UNI_W12 : UNI_W) * 64);
-#define GAS_UNI_GO(SQv, PCM, BUS, W) hipLaunchKernelGGL((k_hrtf_uni<SQv, PCM, BUS, W>), grid, block, 0, stream, g, peak_bits, all, st, tab, twiddles, partials, p_offset, cursors, fade_env, fresh, job, routes, bus_rows, bus_base, commit ? 1u : 0u)
+#define GAS_UNI_GO(SQv, PCM, BUS, W) hipLaunchKernelGGL((k_hrtf_uni<SQv, PCM, BUS, W>), grid, block, 0, stream, g, peak_bits, all, st, tab, twiddles, partials, p_offset, cursors, fade_env, fresh, job, routes, bus_rows, bus_base, commit ? 1u : 0u, nt_hist)
 #define GAS_UNI_CASE(SQv)                      \
 	case SQv:                                  \
 		if (routes) {                          \

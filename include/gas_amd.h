@@ -436,6 +436,10 @@ int gas_bandwidth_probe(gas_ctx *ctx, uint64_t read_bytes, uint64_t write_bytes,
  * the bit.  The build's default: DESIGN.md 3.1; environment variable GAS_UNI12_MIN overrides it at load time.
  * Returns the previous value. */
 uint32_t gas_tune_uni12_min(uint32_t min_sources);
+/* Tuning (process-wide): plain-[HRTF] callbacks of at least `min_sources` sources read and write their history rows
+ * with non-temporal accesses (rows too many to survive in the Infinity Cache from one callback to the next; default
+ * 196608, environment variable GAS_NT_HIST_MIN).  A cache hint only: results do not change.  Returns the previous value. */
+uint32_t gas_tune_nt_hist_min(uint32_t min_sources);
 /* Diagnostic: the processing order the last gas_process_block used for its plain [HRTF] sources (GAS_FLAG_XCD_ORDER
  * only): out[i] = list entry processed i-th; waits for the stream.  GAS_ERR_INVALID_ARGUMENT when that
  * callback ran in list order. */
