@@ -760,7 +760,7 @@ def probe_max_sources(gas, synth, torch, kind, chain, frames, hrir, dirs, sample
     """Largest N (from a fixed ladder) whose p99 callback time stays under 10 ms on one GPU: `samples` synchronous
     callbacks per rung, host clock around gas_process_block + synchronize.  One context sized for the top rung; each
     rung runs the first N slots."""
-    ladder = [1 << 20, 1 << 21, 3 << 20, 1 << 22, 5 << 20, 6 << 20, 7 << 20]
+    ladder = [1 << 20, 1 << 21, 3 << 20, 1 << 22, 5 << 20, 6 << 20, 7 << 20, 15 << 19, 31 << 18]
     top = ladder[-1]
     best = None
     ctx = gas.SpatializerContext(max_sources=top, frames=frames, channel_count=1, flags=gas.capi.FLAG_PEAKS_DRAINING_ONLY)

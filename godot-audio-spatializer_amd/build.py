@@ -9,7 +9,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libgas_amd.so")
-SOURCES = ["gas_ctx.hip", "k_biquad_mix.hip", "k_biquad_pipe.hip", "k_hrtf_ols.hip", "k_hrtf_uni.hip", "k_hrtf_multi.hip", "k_misc.hip", "k_calc_spatialization.hip", "k_sample_sources.hip", "gas_multi.hip", "../host/batched_spatializer_host.cpp"]
+SOURCES = ["gas_ctx.hip", "k_biquad_mix.hip", "k_biquad_pipe.hip", "k_shelf_scan.hip", "k_hrtf_ols.hip", "k_hrtf_uni.hip", "k_hrtf_multi.hip", "k_misc.hip", "k_calc_spatialization.hip", "k_sample_sources.hip", "gas_multi.hip", "../host/batched_spatializer_host.cpp"]
 HEADERS = [os.path.join(CSRC, "gas_internal.h"), os.path.join(CSRC, "gas_device.h"), os.path.join(CSRC, "gas_hrtf_wave.h"), os.path.join(CSRC, "gas_biquad.h"), os.path.join(HERE, "..", "include", "gas_amd.h"), os.path.join(HERE, "..", "include", "gas_amd_host.h")]
 # -fno-slp-vectorize: hipcc's SLP pass packs the FFT butterflies into v_pk_{add,mul,fma}_f32; on gfx950 that
 # costs VGPRs (236 vs 188) and 15 % of k_hrtf_ols' time (measured, profiles/r01 notes), so it stays off.

@@ -425,6 +425,7 @@ struct SrcMeta {
 // with the FFT's LDS exchanges and cost ~16 us per launch when done per source).
 struct LaneMeta {
 	uint32_t slot, row, dir, pdir;
+	uint32_t prow; // row of the peaks array (k_hrtf_uni; == row unless gas_group_args::peak_rows says otherwise)
 	float g0, g1;
 	gas_cursor cur;
 };

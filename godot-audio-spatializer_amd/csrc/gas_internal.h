@@ -59,6 +59,7 @@ struct gas_group_args {
 	uint32_t slot_base;
 	uint32_t n;
 	float *peaks; // [n_rows_total][2]
+	const uint32_t *peak_rows = nullptr; // k_hrtf_uni: [n] row of `peaks` per group entry when it differs from the row of src (a staged chain's last stage reads dense rows but reports into the callback's rows); nullptr = the src row
 	const uint32_t *order = nullptr; // [n] processing order (k_hrtf_ols: entries grouped by HRIR direction; k_hrtf_uni: XCD-affine, k_xcd_order), or nullptr = entry order
 };
 
@@ -120,6 +121,11 @@ struct gas_bus_args {
 // ([C][P][F*2] floats, row stride P_stride).
 uint32_t gas_biquad_partials(uint32_t n); // P for n sources
 hipError_t gas_launch_biquad_mix(hipStream_t stream, int mode, const gas_group_args &g, const gas_dev_state &st, uint32_t frames, uint32_t channel_begin, uint32_t channel_count, float mix_rate, float *partials, uint32_t p_offset, uint32_t p_stride, float *rows_out = nullptr /* non-null: per-source rows instead of the partial mix */, const gas_bus_args &buses = gas_bus_args(), int fx_kind = 0 /* GAS_MODE_FX_FILTER: which GAS_FX_* filter */);
+
+// k_shelf_scan.hip: a rows-out filter stage of a staged chain as a parallel scan over the frames (one wave per source),
+// for callbacks too small to hide the serial recurrence (chosen inside gas_launch_biquad_mix)
+bool gas_shelf_scan_applies(int mode, uint32_t n, uint32_t frames);
+hipError_t gas_launch_shelf_scan(hipStream_t stream, int mode, const gas_group_args &g, const gas_dev_state &st, uint32_t frames, uint32_t chain_pos, float mix_rate, float *rows_out, int fx_kind);
 
 // k_biquad_pipe.hip: the same arithmetic as an eight-wave software pipeline per 32 sources, for callbacks with fewer
 // workgroups than CUs (chosen inside gas_launch_biquad_mix)

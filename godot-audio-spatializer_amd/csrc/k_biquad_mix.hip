@@ -32,6 +32,19 @@
 
 namespace {
 
+#ifndef GAS_BQ_NT
+#define GAS_BQ_NT 1 // the staging loads of the (once-touched) source rows are non-temporal: 65 536 sources 79.8 -> 73.2 us per launch (round 3, profiles/r03_notes.md); no effect at 256 sources
+#endif
+typedef float bq_v4f __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 bq_row_load(const float *p) {
+#if GAS_BQ_NT
+	const bq_v4f v = __builtin_nontemporal_load(reinterpret_cast<const bq_v4f *>(p));
+	return make_float4(v.x, v.y, v.z, v.w);
+#else
+	return *reinterpret_cast<const float4 *>(p);
+#endif
+}
+
 constexpr int SRC_PER_WG = 32;
 #ifndef GAS_BIQUAD_KF
 #define GAS_BIQUAD_KF 32
@@ -71,7 +84,7 @@ __device__ __forceinline__ void run_tiles(LaneState &L, float (&tile)[2][SRC_PER
 	float4 pre[LOADS];
 #pragma unroll
 	for (int q = 0; q < LOADS; q++) {
-		pre[q] = *reinterpret_cast<const float4 *>(ld_base[q]);
+		pre[q] = bq_row_load(ld_base[q]);
 	}
 
 	for (uint32_t tl = 0; tl < n_tiles; tl++) {
@@ -87,7 +100,7 @@ __device__ __forceinline__ void run_tiles(LaneState &L, float (&tile)[2][SRC_PER
 		if (tl + 1 < n_tiles) {
 #pragma unroll
 			for (int q = 0; q < LOADS; q++) {
-				pre[q] = *reinterpret_cast<const float4 *>(ld_base[q] + (size_t)(tl + 1) * KF * 2);
+				pre[q] = bq_row_load(ld_base[q] + (size_t)(tl + 1) * KF * 2);
 			}
 		}
 		__syncthreads();
@@ -422,6 +435,9 @@ bool gas_biquad_uses_pipe(int mode, uint32_t n, uint32_t channel_count, uint32_t
 hipError_t gas_launch_biquad_mix(hipStream_t stream, int mode, const gas_group_args &g, const gas_dev_state &st, uint32_t frames, uint32_t channel_begin, uint32_t channel_count, float mix_rate, float *partials, uint32_t p_offset, uint32_t p_stride, float *rows_out, const gas_bus_args &buses, int fx_kind) {
 	if (g.n == 0) {
 		return hipSuccess;
+	}
+	if (rows_out && channel_count == 1 && g.slots && gas_shelf_scan_applies(mode, g.n, frames)) {
+		return gas_launch_shelf_scan(stream, mode, g, st, frames, channel_begin, mix_rate, rows_out, fx_kind);
 	}
 	dim3 grid(gas_biquad_partials(g.n), channel_count);
 	dim3 block(64);

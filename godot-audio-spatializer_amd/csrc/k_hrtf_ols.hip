@@ -29,6 +29,8 @@
 // table and the output mix are counted once per launch, not per source.  (The full 128-byte gas_params row is NOT
 // part of the figure: the kernel reads its two HRTF fields, one 8-byte load.)  This file keeps the forms with
 // crossfade / direction runs / early reflections / per-source rows; the plain [HRTF] callback runs k_hrtf_uni.hip.
+// source rows non-temporal, like k_hrtf_uni (round 3): the cross-fade form gains 3 %, [ER, HRTF] nothing
+#define GAS_USE_NT 1
 #include "gas_hrtf_wave.h"
 
 namespace {

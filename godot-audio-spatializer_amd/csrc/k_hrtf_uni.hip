@@ -129,6 +129,7 @@ __global__ __launch_bounds__(UW * 64, UW > 8 ? 3 : GAS_HRTF_WAVES_PER_SIMD) void
 		const uint32_t e = my_entry;
 		lm.slot = g.slots ? g.slots[e] : g.slot_base + e; // a contiguous slot range in row order needs no list at all
 		lm.row = g.rows ? g.rows[e] : e;
+		lm.prow = g.peak_rows ? g.peak_rows[e] : lm.row;
 	}
 	gas_audio_frame raw[FQ]; // frames lane + 64 q of the source in flight
 	float rawh[HQ]; // its history samples (lane-major rows: one 16-byte access per lane at F = 512)
@@ -411,7 +412,7 @@ __global__ __launch_bounds__(UW * 64, UW > 8 ? 3 : GAS_HRTF_WAVES_PER_SIMD) void
 		}
 		if constexpr (LEAN) {
 			fft512_ar<false>(zs, t1, t2, lds, lane);
-			products_now(zs, flag, m.row, tslot + ((e - first) & 1u) * 256);
+			products_now(zs, flag, (uint32_t)__builtin_amdgcn_readlane((int)lm.prow, (int)(e - first)), tslot + ((e - first) & 1u) * 256);
 		} else {
 			fft512<false>(zs, t1, t2, lds, lane);
 			// the products of a transform are taken one transform later (measured: taking them in front of the next
@@ -423,7 +424,7 @@ __global__ __launch_bounds__(UW * 64, UW > 8 ? 3 : GAS_HRTF_WAVES_PER_SIMD) void
 			}
 			have_prev = true;
 			prev_flag = flag;
-			prev_row = m.row;
+			prev_row = (uint32_t)__builtin_amdgcn_readlane((int)lm.prow, (int)(e - first)); // where this source's peak goes
 			if constexpr (BUS2) {
 				const int i = (int)(e - first);
 				pw0l = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_w0l), i));
@@ -439,7 +440,7 @@ __global__ __launch_bounds__(UW * 64, UW > 8 ? 3 : GAS_HRTF_WAVES_PER_SIMD) void
 	if (have && (!BUS2 || commit)) {
 		st.hrtf_prev_gain[lm.slot] = lm.g1;
 		if (!my_flag) { // "not measured": never passes the gate (audio_spatializer.cpp:464-469)
-			*reinterpret_cast<float2 *>(g.peaks + (size_t)lm.row * 2) = make_float2(__builtin_inff(), __builtin_inff());
+			*reinterpret_cast<float2 *>(g.peaks + (size_t)lm.prow * 2) = make_float2(__builtin_inff(), __builtin_inff());
 		}
 		if (fresh) { // device-published parameter rows go through to the slot table (saves the scatter launch)
 			const float4 *src4 = reinterpret_cast<const float4 *>(fresh + lm.row);

@@ -204,3 +204,46 @@ def test_engine_effect_settings_do_not_survive_a_slot(gas, ob):
     with pytest.raises(gas.GasError):
         with gas.SpatializerContext(max_sources=2, frames=F) as ctx:
             ctx.source_alloc_many(1, gas.capi.KIND_EFFECT, (10,))  # unknown kind
+
+
+@pytest.mark.parametrize("chain,frames", [((HS, HRTF), 512), ((LP, HRTF), 256), ((HS,), 512), ((NOTCH, HP), 128)])
+def test_filter_stage_as_a_scan_matches_oracle(gas, ob, chain, frames, monkeypatch):
+    """From 512 sources on (and below 32768) a rows-out filter stage runs k_shelf_scan: one wave per source, the block's
+    recurrence split over the lanes and stitched by an affine scan -- another rounding than the engine's serial loop, so
+    this is the test that says how far apart they are: the mix to TOL, a single source's peak to 2e-5 where the poles
+    are well inside the unit circle (the default 5 kHz shelf: ~2e-6 measured).  Sources whose poles are close to it
+    (r^2 > 0.9) take the kernel's serial path; some are mixed in here.  The same callbacks with GAS_SHELF_SCAN=0 (the
+    serial stage kernel) are the control."""
+    from godot_audio_spatializer_amd import synth
+
+    n = 1500
+    hrir = _hrir() if HRTF in chain else None
+    for scan in ("1", "0"):
+        monkeypatch.setenv("GAS_SHELF_SCAN", scan)
+        rng = np.random.default_rng(31)
+        with gas.SpatializerContext(max_sources=n, frames=frames) as ctx:
+            if hrir is not None:
+                ctx.hrtf_load(hrir)
+            slots = ctx.source_alloc_many(n, gas.capi.KIND_EFFECT, chain)
+            ora = ob.BatchOracle(ob.KIND_EFFECT, n, frames, chain=chain, hrir=hrir)
+            worst = 0.0
+            for b in range(6):
+                if b % 2 == 0:
+                    p = synth.draw_params(rng, n, dirs=32, frames=frames)
+                    p["fx_shelf_cutoff_hz"] = np.exp(rng.uniform(np.log(800.0), np.log(12000.0), n)).astype(np.float32)
+                    p["fx_shelf_cutoff_hz"][::97] = 60.0  # poles next to the unit circle: the serial path
+                    ctx.params_publish_batch(slots, p)
+                    st = ctx.fx_settings_defaults(n)
+                    st["filter_cutoff_hz"] = np.exp(rng.uniform(np.log(500.0), np.log(12000.0), (n, 4)))
+                    st["filter_cutoff_hz"][::89] = 90.0
+                    st["filter_resonance"] = rng.uniform(0.4, 1.2, (n, 4))
+                    ctx.fx_settings_publish(slots, st)
+                    for s_ in range(n):
+                        for j in range(len(chain)):
+                            ora.set_fx_settings(s_, j, st["filter_cutoff_hz"][s_, j], st["filter_resonance"][s_, j], 1.0, 0.0)
+                src = synth.draw_sources(rng, n, frames)
+                mix, peaks = ctx.process_block(src, slots)
+                _, rpeaks, r64 = ora.block(p.astype(ob.PARAMS_DTYPE), src, want64=True)
+                worst = max(worst, rel_rms(mix[0], r64[0]))
+                assert rel_rms(mix[0], r64[0]) <= TOL, f"scan={scan} block {b}"
+                np.testing.assert_allclose(peaks, rpeaks, rtol=1e-4, atol=1e-6, err_msg=f"scan={scan} block {b}")
