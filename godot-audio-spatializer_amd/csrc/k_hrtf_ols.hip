@@ -284,6 +284,7 @@ __device__ __forceinline__ void hrtf_body(float2 *lds_all, float2 *tw_lds, const
 			const uint32_t er_pos = st.er_pos[m.slot];
 			gas_audio_frame *ring = st.er_ring + (size_t)m.slot * er_R;
 			float *xs = reinterpret_cast<float *>(lds);
+#ifndef GAS_ER_PAIRS // the product form: a lane owns frames lane + 64 q, 8-byte accesses, 16 tap loads in flight (two round trips per source at F = 256)
 #pragma unroll 2 // 16 tap loads in flight per trip (4 spills, 1 serialises four round trips per source)
 			for (int q = 0; q < FQ; q++) {
 				const int f = lane + 64 * q;
@@ -303,6 +304,58 @@ __device__ __forceinline__ void hrtf_body(float2 *lds_all, float2 *tw_lds, const
 				}
 				xs[f] = (yl + yr) * 0.5f;
 			}
+#else
+			// EXPERIMENT (round 3, -DGAS_ER_PAIRS, measured SLOWER: cfg5 27.2 vs 22.6 us per launch): a lane owns frame PAIRS
+			// (2 lane, 2 lane + 1) + 128 qq, so the row, the ring store and every tap are 16-byte accesses and the 8 tap
+			// loads of a pass are all in flight at once.  The gathers are 6.6 of the launch's 22.6 us (with them removed the
+			// launch takes 16.0), but halving their instruction count does not pay: odd delays make the 16-byte loads
+			// 8-byte-aligned only, the per-lane pointer selects and the straddle fix-ups add VALU work in front of them.
+			// The results pass through xs[] by frame index, and each frame adds its taps in tap order: the same bits.  A pair straddles the row / ring boundary (first frame still in the ring, second already in
+			// the row: i == -1) or the ring's wrap (ring index er_R - 1) only for odd delays, in one lane per tap: those lanes
+			// fetch their second frame separately.
+			typedef float er_v4f __attribute__((ext_vector_type(4)));
+#pragma unroll
+			for (int qq = 0; qq < FQ / 2; qq++) {
+				const int f0 = 2 * lane + 128 * qq;
+				const er_v4f fr2 = *reinterpret_cast<const er_v4f *>(&srow[f0]);
+				*reinterpret_cast<er_v4f *>(&ring[(er_pos + (uint32_t)f0) & (er_R - 1)]) = fr2; // this block into the ring (er_pos, f0 even: no wrap inside a pair)
+				er_v4f xp2[GAS_ER_TAPS];
+				bool fix[GAS_ER_TAPS];
+				const gas_audio_frame *second[GAS_ER_TAPS];
+#pragma unroll
+				for (int k = 0; k < GAS_ER_TAPS; k++) {
+					const uint32_t du = P->er_delay[k];
+					const int d = (int)(du < er_R - F ? du : er_R - F); // keeps every tap inside row/ring
+					const int i = f0 - d; // first frame of the pair, relative to this callback's row
+					const uint32_t j = (er_pos + (uint32_t)(i + (int)er_R)) & (er_R - 1); // its ring index when i < 0
+					const gas_audio_frame *p0 = i >= 0 ? &srow[i] : &ring[j];
+					// the pair is contiguous unless it straddles row / ring (i == -1) or the ring's end (j == er_R - 1, i < -1)
+					fix[k] = i == -1 || (i < -1 && j == er_R - 1);
+					second[k] = i + 1 >= 0 ? &srow[i + 1] : &ring[(j + 1) & (er_R - 1)];
+					xp2[k] = *reinterpret_cast<const er_v4f *>(fix[k] ? reinterpret_cast<const gas_audio_frame *>(&srow[f0]) : p0); // (a straddling lane loads something harmless here)
+				}
+				float yl0 = fr2.x, yr0 = fr2.y, yl1 = fr2.z, yr1 = fr2.w;
+#pragma unroll
+				for (int k = 0; k < GAS_ER_TAPS; k++) {
+					const float gk = P->er_gain[k];
+					er_v4f x2 = xp2[k];
+					if (fix[k]) { // one lane per tap at most (odd delays): both frames by 8-byte loads
+						const uint32_t du = P->er_delay[k];
+						const int d = (int)(du < er_R - F ? du : er_R - F);
+						const int i = f0 - d;
+						const uint32_t j = (er_pos + (uint32_t)(i + (int)er_R)) & (er_R - 1);
+						const gas_audio_frame a = i >= 0 ? srow[i] : ring[j];
+						const gas_audio_frame b2 = *second[k];
+						x2 = er_v4f{ a.left, a.right, b2.left, b2.right };
+					}
+					yl0 = yl0 + gk * x2.x;
+					yr0 = yr0 + gk * x2.y;
+					yl1 = yl1 + gk * x2.z;
+					yr1 = yr1 + gk * x2.w;
+				}
+				*reinterpret_cast<float2 *>(&xs[f0]) = make_float2((yl0 + yr0) * 0.5f, (yl1 + yr1) * 0.5f);
+			}
+#endif
 			if (lane == 0) {
 				st.er_pos[m.slot] = (er_pos + F) & (er_R - 1);
 			}
