@@ -38,6 +38,10 @@
 #define GAS_UNI12_DEFAULT_MIN 0 // sources from which the twelve-wave form is the default (0 = only on request)
 #endif
 
+#ifndef GAS_UNI12_DIRECT
+#define GAS_UNI12_DIRECT 0 // EXPERIMENT: the twelve-wave form takes the HRIR row straight from the L2 into registers at the top of the trip (no LDS table slots, no LDS-DMA): the third wave per SIMD without the extra 8 KiB of LDS traffic per source
+#endif
+
 namespace {
 
 #ifdef GAS_STAMPS
@@ -189,7 +193,7 @@ __global__ __launch_bounds__(UW * 64, UW > 8 ? 3 : GAS_HRTF_WAVES_PER_SIMD) void
 			__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(row + p * 64), (__attribute__((address_space(3))) void *)(dst + p * 64), 16, 0, 0);
 		}
 	};
-	if constexpr (LEAN) {
+	if constexpr (LEAN && !GAS_UNI12_DIRECT) {
 		if (first < last) {
 			table_dma((uint32_t)__builtin_amdgcn_readlane((int)lm.dir, 0), 0u);
 		}
@@ -239,9 +243,18 @@ __global__ __launch_bounds__(UW * 64, UW > 8 ? 3 : GAS_HRTF_WAVES_PER_SIMD) void
 	float pw0l = 1.0f, pw0r = 1.0f, pw1l = 0.0f, pw1r = 0.0f; // BUS2: the previous source's bus weights (wave-uniform)
 
 	// LEAN: the products of a source right after its transform, its row read from the wave's LDS slot (slot_read_spectra)
+	float4 hd[LEAN && GAS_UNI12_DIRECT ? 8 : 1]; // GAS_UNI12_DIRECT: this source's row, requested at the top of its trip
 	auto products_now = [&](const float2(&z)[8], uint32_t flag, uint32_t row, const float4 *slot) {
 		float4 h[8];
-		slot_read_spectra(slot, lane, h);
+		if constexpr (LEAN && GAS_UNI12_DIRECT) {
+#pragma unroll
+			for (int j = 0; j < 8; j++) {
+				h[j] = hd[j];
+			}
+			finish_spectra(lane, h);
+		} else {
+			slot_read_spectra(slot, lane, h);
+		}
 #pragma unroll
 		for (int j = 0; j < 8; j++) {
 			cmac_fixed(aYL[j], z[j], h[j].x, h[j].y);
@@ -261,7 +274,9 @@ __global__ __launch_bounds__(UW * 64, UW > 8 ? 3 : GAS_HRTF_WAVES_PER_SIMD) void
 			for (int j = 0; j < 8; j++) {
 				y[j] = cmul_fixed(z[j], ear == 0 ? h[j].x : h[j].z, ear == 0 ? h[j].y : h[j].w);
 			}
-			asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the compiler's ds_reads below would wait for the DMA anyway
+			if (!GAS_UNI12_DIRECT) {
+				asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the compiler's ds_reads below would wait for the DMA anyway
+			}
 			fft512_twlds<true>(y, tw_lds, lds, lane);
 			float p = 0.0f;
 #pragma unroll
@@ -352,7 +367,7 @@ __global__ __launch_bounds__(UW * 64, UW > 8 ? 3 : GAS_HRTF_WAVES_PER_SIMD) void
 		const SrcMeta m = bcast_meta<SRC_PCM>(lm, e - first, F);
 		const SrcMeta mn = bcast_meta<SRC_PCM>(lm, has_next ? e + 1 - first : e - first, F);
 		const uint32_t flag = (uint32_t)__builtin_amdgcn_readlane((int)my_flag, (int)(e - first));
-		if constexpr (LEAN) {
+		if constexpr (LEAN && !GAS_UNI12_DIRECT) {
 			// Everything this trip consumes has landed: the frames and history requested a trip ago, and -- older than
 			// those in the wave's vector-memory queue, which retires in order -- this source's table row.  The next
 			// source's row starts for the other slot now and has the whole trip to arrive.
@@ -360,6 +375,9 @@ __global__ __launch_bounds__(UW * 64, UW > 8 ? 3 : GAS_HRTF_WAVES_PER_SIMD) void
 			if (has_next) {
 				table_dma(mn.dir, e + 1 - first);
 			}
+		}
+		if constexpr (LEAN && GAS_UNI12_DIRECT) {
+			issue_spectra(tab.spec, m.dir, lane, hd); // lands under the window and the transform
 		}
 
 		// x_full[lane + 64 q]: q < HQ from the history, the rest from this callback's frames
@@ -411,7 +429,11 @@ __global__ __launch_bounds__(UW * 64, UW > 8 ? 3 : GAS_HRTF_WAVES_PER_SIMD) void
 			zs[j] = make_float2(xq[j], xq[j + SQ]);
 		}
 		if constexpr (LEAN) {
-			fft512_ar<false>(zs, t1, t2, lds, lane);
+			if constexpr (GAS_UNI12_DIRECT) {
+				fft512<false>(zs, t1, t2, lds, lane);
+			} else {
+				fft512_ar<false>(zs, t1, t2, lds, lane);
+			}
 			products_now(zs, flag, (uint32_t)__builtin_amdgcn_readlane((int)lm.prow, (int)(e - first)), tslot + ((e - first) & 1u) * 256);
 		} else {
 			fft512<false>(zs, t1, t2, lds, lane);
