@@ -550,6 +550,7 @@ class BatchedSpatializerHost:
         L.gas_host_is_playback_paused.argtypes = [vp, u32]
         L.gas_host_get_playback_position.argtypes = [vp, u32, C.POINTER(C.c_uint64)]
         L.gas_host_get_mixed_frames.argtypes = [vp, i32, vp, i32]
+        L.gas_host_set_effect_settings.argtypes = [vp, u32, vp]
         L.gas_host_set_release_fn.argtypes = [vp, vp, vp]
         L.gas_host_collect_released.argtypes = [vp]
         L.gas_host_set_process_effects_fn.argtypes = [vp, vp, vp]
@@ -627,6 +628,10 @@ class BatchedSpatializerHost:
         if rc != -3:
             self.ctx._check(rc, "gas_host_set_spatializer_parameters")
         return rc
+
+    def set_effect_settings(self, pid, settings):
+        f = np.ascontiguousarray(settings, dtype=FX_SETTINGS_DTYPE).reshape(1)
+        return self.lib.gas_host_set_effect_settings(self.h, pid, _np_ptr(f))
 
     def is_playback_active(self, pid):
         return bool(self.lib.gas_host_is_playback_active(self.h, pid))

@@ -77,10 +77,11 @@ struct Playback {
 };
 
 struct Command {
-	enum Kind { START, PARAMS } kind = START;
+	enum Kind { START, PARAMS, FX_SETTINGS } kind = START;
 	uint32_t id = 0;
 	std::unique_ptr<Playback> playback; // START
 	gas_params params{}; // PARAMS
+	gas_fx_settings fx_settings{}; // FX_SETTINGS
 };
 
 // [ENGINE] Math::db_to_linear
@@ -218,6 +219,11 @@ struct gas_host {
 				// request mixes; here a playback is only ever adopted inside the request that starts a new mix)
 				by_id[pb->id] = pb.get();
 				list.push_back(std::move(pb)); // newest = last (walked from the back)
+			} else if (c.kind == Command::FX_SETTINGS) {
+				auto it = by_id.find(c.id);
+				if (it != by_id.end()) {
+					gas_fx_settings_publish(ctx, &it->second->slot, &c.fx_settings, 1); // snapshotted with the parameters (:328)
+				}
 			} else {
 				auto it = by_id.find(c.id);
 				if (it == by_id.end()) {
@@ -395,6 +401,8 @@ int gas_host_create(gas_ctx *ctx, int kind, const int32_t *effects, uint32_t n_e
 	h->ctx_pairs = (int)cfg.channel_count;
 	h->pairs_visible = kind == GAS_KIND_3D_MIX ? (int)cfg.channel_count : 1;
 	h->effects.assign(effects, effects + n_effects);
+	h->list.reserve(1024); // starts do not reallocate on the audio thread until the population passes these
+	h->by_id.reserve(2048);
 	// ramp k = 0.96^(k+1) * (64 - k) / 64, built with the reference's f32 operations in its order
 	float coefficient = 1.0f, step = 0.0f;
 	for (int k = 0; k < TAIL; k++) {
@@ -498,6 +506,22 @@ int gas_host_set_spatializer_parameters(gas_host *h, uint32_t id, const gas_para
 	c.kind = Command::PARAMS;
 	c.id = id;
 	c.params = *params;
+	std::lock_guard<std::mutex> lk(h->inbox_mu);
+	h->inbox.push_back(std::move(c));
+	return GAS_OK;
+}
+
+int gas_host_set_effect_settings(gas_host *h, uint32_t id, const gas_fx_settings *settings) {
+	if (!h || !h->lookup(id)) {
+		return GAS_ERR_BAD_SLOT;
+	}
+	if (!settings) {
+		return GAS_ERR_INVALID_ARGUMENT;
+	}
+	Command c;
+	c.kind = Command::FX_SETTINGS;
+	c.id = id;
+	c.fx_settings = *settings;
 	std::lock_guard<std::mutex> lk(h->inbox_mu);
 	h->inbox.push_back(std::move(c));
 	return GAS_OK;

@@ -11,7 +11,7 @@
  *
  * Threading contract (the reference's split, audio_spatializer.h:135-138, with its SafeList / SafeFlag / Mutex roles):
  *   - control entries -- gas_host_start_playback*, gas_host_stop_playback, gas_host_set_spatializer_parameters,
- *     gas_host_set_playback_disable_threshold_db, gas_host_is_playback_active, gas_host_set_playback_paused,
+ *     gas_host_set_effect_settings, gas_host_set_playback_disable_threshold_db, gas_host_is_playback_active, gas_host_set_playback_paused,
  *     gas_host_is_playback_paused, gas_host_get_playback_position, gas_host_playback_count, gas_host_set_release_fn,
  *     gas_host_collect_released, gas_host_set_process_effects_fn -- may be
  *     called from any number of threads (main, physics) at any time, concurrently with the audio thread.  They only
@@ -55,6 +55,9 @@ int gas_host_start_playback_device_stream(gas_host *host, uint32_t stream, uint6
 int gas_host_stop_playback(gas_host *host, uint32_t id);
 /* set_spatializer_parameters (audio_spatializer.cpp:558-564), per playback. */
 int gas_host_set_spatializer_parameters(gas_host *host, uint32_t id, const gas_params *params);
+/* Settings of the playback's engine-effect kinds (GAS_FX_LOWPASS .. GAS_FX_AMPLIFY, by chain position): what a script
+ * writes to the AudioEffect resources; queued like the parameters, in the order issued.  Control thread. */
+int gas_host_set_effect_settings(gas_host *host, uint32_t id, const gas_fx_settings *settings);
 void gas_host_set_playback_disable_threshold_db(gas_host *host, float db); /* audio_spatializer.h:87 */
 int gas_host_is_playback_active(gas_host *host, uint32_t id);
 /* set_playback_paused / is_playback_paused (audio_spatializer.cpp:115-122, :161-170), PER PLAYBACK: the reference

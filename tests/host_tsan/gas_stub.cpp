@@ -61,6 +61,11 @@ int gas_source_alloc(gas_ctx *c, int, const int32_t *, uint32_t, uint32_t *out_s
 	return GAS_ERR_OUT_OF_SLOTS;
 }
 
+int gas_fx_settings_publish(gas_ctx *c, const uint32_t *, const gas_fx_settings *, uint32_t) {
+	std::lock_guard<std::mutex> lk(c->params_mu); // like the real one: under the parameter lock
+	return GAS_OK;
+}
+
 int gas_source_free(gas_ctx *c, uint32_t slot) {
 	std::lock_guard<std::mutex> lk(c->alloc_mu);
 	if (slot >= c->cfg.max_sources || !c->used[slot]) {

@@ -83,6 +83,9 @@ int main(int argc, char **argv) {
 				uint64_t pos = 0;
 				(void)gas_host_get_playback_position(host, id, &pos);
 				gas_host_set_playback_paused(host, id, 0);
+				gas_fx_settings fs{};
+				fs.filter_cutoff_hz[0] = 1000.0f;
+				gas_host_set_effect_settings(host, id, &fs);
 			}
 			// the context's slot allocator is open to control threads too (gas_amd.h): a throw-away slot per loop
 			uint32_t probe = 0;

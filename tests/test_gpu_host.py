@@ -194,6 +194,49 @@ def test_host_process_effects_hook_and_release(gas, ob):
         assert sorted(released) == sorted((ids[i], 1000 + i) for i in range(n))
 
 
+def test_host_engine_effect_chain_with_settings(gas, ob):
+    """The batched host over a chain of the engine-effect kinds: gas_host_set_effect_settings queues a playback's
+    settings like its parameters (what a script writes to the AudioEffect resources); ends, fade-outs and the gate as
+    for every other chain."""
+    from godot_audio_spatializer_amd import synth
+
+    K = gas.capi
+    F, lengths = 256, [700, 1900, 1300, 2600]
+    chain, ochain = (K.FX_LOWPASS, K.FX_AMPLIFY), (ob.FX_LOWPASS, ob.FX_AMPLIFY)
+    rng = np.random.default_rng(12)
+    streams = [rng.uniform(-0.5, 0.5, (m, 2)).astype(np.float32) for m in lengths]
+    params = synth.draw_params(rng, len(lengths), dirs=8, frames=F)
+    with gas.SpatializerContext(max_sources=8, frames=F) as ctx:
+        host = K.BatchedSpatializerHost(ctx, K.KIND_EFFECT, chain)
+        ids = [None] * len(lengths)
+        for i in reversed(range(len(lengths))):
+            ids[i] = host.start_playback_array(streams[i])
+            host.set_spatializer_parameters(ids[i], params[i])
+        rig = Rig(ob, ob.KIND_EFFECT, streams, F, chain=ochain)
+        rig.params[:] = params.astype(ob.PARAMS_DTYPE)
+        for i in range(len(lengths)):
+            for j in range(2):
+                fx = rig.pbs[i].pdfx.fx[j]
+                fx.cutoff_hz, fx.resonance, fx.gain, fx.volume_db = 2000.0, 0.5, 1.0, 0.0
+        for cb in range(14):
+            if cb in (1, 4, 7):
+                for i in range(len(lengths)):
+                    st = ctx.fx_settings_defaults(1)
+                    st["filter_cutoff_hz"][0, 0] = 400.0 * (i + 1) * (cb + 1)
+                    st["filter_resonance"][0, 0] = 0.5 + 0.1 * i
+                    st["amplify_volume_db"][0, 1] = -3.0 * i - cb
+                    assert host.set_effect_settings(ids[i], st) in (0, -3)  # -3: ended and reaped meanwhile
+                    fx0, fx1 = rig.pbs[i].pdfx.fx[0], rig.pbs[i].pdfx.fx[1]
+                    fx0.cutoff_hz, fx0.resonance = float(st["filter_cutoff_hz"][0, 0]), float(st["filter_resonance"][0, 0])
+                    fx1.volume_db = float(st["amplify_volume_db"][0, 1])
+            rc, got = host.get_mixed_frames(0, F)
+            orc, want = rig.get_mixed_frames(0)
+            assert rc == 0 and orc == 0 and mix_matches(got, want), f"callback {cb}"
+            for i in range(len(lengths)):
+                assert host.is_playback_active(ids[i]) == bool(rig.pbs[i].active), f"callback {cb} playback {i}"
+        host.close()
+
+
 def test_host_modes_do_not_mix(gas):
     with gas.SpatializerContext(max_sources=4, frames=512) as ctx:
         host = gas.capi.BatchedSpatializerHost(ctx, gas.capi.KIND_EFFECT)
