@@ -107,13 +107,15 @@ def _run_multi(gas, ob, devices, device_memory):
     return got, want
 
 
+@pytest.mark.parametrize("threads", ["0", "1"])
 @pytest.mark.parametrize("direct", ["1", "0"])
-def test_multi_device_memory_entry_on_one_gpu(gas, ob, direct, monkeypatch):
+def test_multi_device_memory_entry_on_one_gpu(gas, ob, direct, threads, monkeypatch):
     """gas_multi_process_block_mem(GAS_MEM_DEVICE): no staging, no host wait, gather buffer reuse guarded by the root's
     event -- five queued callbacks over three shards of the one GPU equal the single-context mixes.  direct = 1: every
     shard's own final sum writes its row of the root's gather buffer (SURVEY 8e's all-to-one direct write); 0: the
     hipMemcpyPeerAsync form."""
     monkeypatch.setenv("GAS_MULTI_DIRECT", direct)
+    monkeypatch.setenv("GAS_MULTI_THREADS", threads)  # 1: one enqueue thread per shard beyond the first
     got, want = _run_multi(gas, ob, [0, 0, 0], device_memory=True)
     for g, w in zip(got, want):
         assert rel_rms(g[0], w[0]) <= TOL
