@@ -256,7 +256,9 @@ class Runner:
         self.B = B = max(1, bucket)
         self.buckets = [torch.zeros(B, 1, frames, 2, device="cuda") for _ in range(2)]
         self.peaks = torch.zeros(n_local, 2, device="cuda")
-        self.comm_stream = torch.cuda.Stream() if env["world"] > 1 else None
+        # buckets: the collective beside the compute stream (its ~50 us of host time are spread over the bucket); one or two
+        # callbacks per reduce: a plain stream-ordered call (~10 us of host time)
+        self.comm_stream = torch.cuda.Stream() if env["world"] > 1 and B > 2 else None
         self.reducer = sharding.PartialMixReducer(env["dist"] if env["world"] > 1 else None, root=0, comm_stream=self.comm_stream)
         self.pending = [None, None]
         self.owed = [False, False]
@@ -578,7 +580,7 @@ def main():
                 "host_enqueue_us_per_step": enq_ms / args.steps * 1e3,
                 "peaks": peaks_desc,
                 "experiment": experiment,
-                "parallelism": (f"source-sharded x{world} (world {world}, this rank on cuda:{local_rank}, {backend} reports {rccl_ranks} ranks), sum-reduce to rank 0 of {run.B} callbacks' partial mixes ({run.B * frames * 8} B) per collective on a side stream" + (" -- throughput arrangement: a callback's mix reaches rank 0 up to that many callbacks later; --reduce-bucket 1 is the real-time arrangement" if run.B > 1 else "")) if world > 1 else "single GPU (world 1, cuda:%d)" % local_rank,
+                "parallelism": (f"source-sharded x{world} (world {world}, this rank on cuda:{local_rank}, {backend} reports {rccl_ranks} ranks), sum-reduce to rank 0 of {run.B} callbacks' partial mixes ({run.B * frames * 8} B) per collective" + (" on a side stream" if run.comm_stream is not None else " (stream-ordered on the compute stream)") + (" -- throughput arrangement: a callback's mix reaches rank 0 up to that many callbacks later; --reduce-bucket 1 is the real-time arrangement" if run.B > 1 else "")) if world > 1 else "single GPU (world 1, cuda:%d)" % local_rank,
                 "reduce_bucket": run.B,
                 "realtime_budget_ms": frames / 48000.0 * 1e3,
             },

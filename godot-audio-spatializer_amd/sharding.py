@@ -33,7 +33,13 @@ class PartialMixReducer:
     """Sum-reduce of the per-GPU partial mixes to `root`, optionally pipelined one callback deep.
 
     reduce(t): starts the reduce of tensor t (in place on root) and returns a handle;
-    the caller must wait(handle) before reading t on root or reusing t anywhere."""
+    the caller must wait(handle) before reading t on root or reusing t anywhere.
+
+    Two arrangements (host cost measured with tools/reduce_launch_probe.py, nccl, 4 KiB): with a `comm_stream` the
+    collective runs beside the compute stream (async_op + wait: ~50 us of host time per reduce -- for BUCKETS of
+    callbacks, where that is spread over the bucket); without one it is a plain stream-ordered call on the current
+    stream (~8-12 us of host time, the compute stream waits for the collective -- for the real-time arrangement, one
+    reduce per callback, where 50 us of host time per 20 us callback would be the bottleneck)."""
 
     def __init__(self, dist, root=0, comm_stream=None):
         self.dist = dist
@@ -57,7 +63,8 @@ class PartialMixReducer:
             self.comm_stream.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self.comm_stream):
                 return self.dist.reduce(t, dst=self.root, op=self.dist.ReduceOp.SUM, async_op=True)
-        return self.dist.reduce(t, dst=self.root, op=self.dist.ReduceOp.SUM, async_op=True)
+        self.dist.reduce(t, dst=self.root, op=self.dist.ReduceOp.SUM)  # stream-ordered on the current stream (nccl); synchronous on gloo
+        return None
 
     @staticmethod
     def wait(handle):

@@ -16,15 +16,19 @@ torch.cuda.set_device(0)
 dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
 t = torch.zeros(1, 512, 2, device="cuda")
 side = torch.cuda.Stream()
-for mode in ("current stream, blocking call", "side stream, async_op + wait (bench.py's PartialMixReducer)"):
+for mode in ("current stream, blocking call", "current stream, async_op + wait (the collective runs on the process group's own stream)", "side stream, async_op + wait (round 2's PartialMixReducer)"):
     for _ in range(50):
         dist.reduce(t, dst=0)
     torch.cuda.synchronize()
     n = 2000
     t0 = time.perf_counter()
-    if mode.startswith("current"):
+    if mode.startswith("current stream, blocking"):
         for _ in range(n):
             dist.reduce(t, dst=0)
+    elif mode.startswith("current stream, async"):
+        for _ in range(n):
+            h = dist.reduce(t, dst=0, async_op=True)
+            h.wait()
     else:
         for _ in range(n):
             side.wait_stream(torch.cuda.current_stream())
