@@ -46,6 +46,7 @@ WORKLOADS = {
     "hrtf4096": (2, (3,), 512, 4096, 0, "cfg3: 4096 sources, 256-tap HRTF overlap-save FFT -> stereo, 512-frame @48kHz"),
     "biquad": (0, (), 512, 256, 0, "cfg2: 256 sources, pan + distance high-shelf biquad (mix_channel), 512-frame @48kHz"),
     "erhrtf": (2, (2, 3), 256, 4096, 4096, "cfg5: 4096 sources, 8-tap early reflections + HRTF chain, 256-frame @48kHz"),
+    "hrtf4096_f256": (2, (3,), 256, 4096, 0, "comparison for cfg5 (not a BASELINE config): 4096 sources, HRTF alone, 256-frame @48kHz"),
 }
 HBM_PEAK = 8.0e12  # MI355X_MICROARCH.md: 8 TB/s spec
 N_SRC_BUFFERS_BYTES = int(os.environ.get("GAS_BENCH_SRC_BYTES", 320 << 20))  # rotate source buffers over > 256 MiB so the Infinity Cache cannot hold them (the override is a cache experiment, never the headline)

@@ -215,6 +215,7 @@ struct gas_ctx {
 	uint32_t prof_k = 1;
 	int prof_group = -1;
 	bool prof_uni = false; // the timed launch was k_hrtf_uni
+	bool uni_er_enabled = getenv("GAS_UNI_ER") == nullptr || atoi(getenv("GAS_UNI_ER")) != 0; // [ER, HRTF] through k_hrtf_uni<ER> (0: k_hrtf_ols<ER>, the previous form, kept for comparison)
 	bool prof_pipe = false; // the timed launch was k_biquad_pipe
 	double ev_overhead_ms = 0.0; // marker/dispatch overhead of an event pair around one launch (calibrated)
 	uint32_t prof_every = 1, prof_tick = 0; // bracket every Nth callback's dominant launch
@@ -334,7 +335,7 @@ inline uint32_t range_partials(const ChainRange &r, bool staged_uni) {
 }
 
 // Partial mixes each launch group writes (must mirror the launchers' grids).
-void plan_partials(const Group *groups, const std::vector<ChainRange> &ranges, uint32_t *pcount, bool uni_hrtf, bool staged_uni) {
+void plan_partials(const Group *groups, const std::vector<ChainRange> &ranges, uint32_t *pcount, bool uni_hrtf, bool staged_uni, bool uni_er) {
 	for (int gt = 0; gt < G_COUNT; gt++) {
 		pcount[gt] = 0;
 	}
@@ -350,6 +351,11 @@ void plan_partials(const Group *groups, const std::vector<ChainRange> &ranges, u
 	}
 	if (uni_hrtf && groups[G_FX_HRTF].count && !groups[G_FX_HRTF_PK].count) {
 		pcount[G_FX_HRTF] = gas_hrtf_uni_partials(groups[G_FX_HRTF].count); // k_hrtf_uni's own grid
+	}
+	if (uni_er && groups[G_FX_ER_HRTF].count + groups[G_FX_ER_HRTF_PK].count) { // [ER, HRTF] in k_hrtf_uni<ER>: both groups in one list
+		const int lead = groups[G_FX_ER_HRTF].count ? G_FX_ER_HRTF : G_FX_ER_HRTF_PK;
+		pcount[G_FX_ER_HRTF] = pcount[G_FX_ER_HRTF_PK] = 0;
+		pcount[lead] = gas_hrtf_uni_partials(groups[G_FX_ER_HRTF].count + groups[G_FX_ER_HRTF_PK].count);
 	}
 	if (groups[G_FX_GENERIC].count) {
 		for (const ChainRange &r : ranges) {
@@ -473,7 +479,10 @@ int run_groups(gas_ctx *c, const gas_audio_frame *d_src, const uint32_t *d_slots
 	uint32_t pcount[G_COUNT];
 	const bool uni_hrtf = groups == c->groups && uni_ok(c);
 	const bool staged_uni = uni_ok(c) && c->run_buses == nullptr && gas_hrtf_uni_waves() == 8; // staged chains ending in the HRTF: last stage = k_hrtf_uni
-	plan_partials(groups, ranges, pcount, uni_hrtf, staged_uni);
+	// [ER, HRTF] through k_hrtf_uni<ER> (22.5 -> see profiles/r03_notes.md): the exact-peak group's entries follow the
+	// frequency-domain group's in the callback's list, so one launch covers both
+	const bool uni_er = uni_ok(c) && c->run_buses == nullptr && gas_hrtf_uni_waves() == 8 && c->uni_er_enabled && (groups[G_FX_ER_HRTF].count == 0 || groups[G_FX_ER_HRTF_PK].count == 0 || groups[G_FX_ER_HRTF].offset + groups[G_FX_ER_HRTF].count == groups[G_FX_ER_HRTF_PK].offset);
+	plan_partials(groups, ranges, pcount, uni_hrtf, staged_uni, uni_er);
 	uint32_t p_total = 0, p_mix = 0;
 	for (int gt = 0; gt < G_COUNT; gt++) {
 		p_total += pcount[gt];
@@ -635,6 +644,21 @@ int run_groups(gas_ctx *c, const gas_audio_frame *d_src, const uint32_t *d_slots
 					job = gas_deferred_reduce();
 					break;
 				}
+				if (fd_gt == G_FX_ER_HRTF && uni_er) {
+					gas_group_args gu = ga; // this group's entries, then (frequency-domain group first) the exact-peak group's
+					gu.n = is_pk ? gr.count : gr.count + gp.count;
+					const bool whole = groups[gt].contiguous && (is_pk || gp.count == 0 || (gp.contiguous && gp.slot_base == gr.slot_base + gr.count));
+					if (whole) {
+						gu.slots = nullptr;
+						gu.slot_base = groups[gt].slot_base;
+					}
+					e = gas_launch_hrtf_uni(c->stream, gu, nullptr, is_pk, c->st, c->tab, c->d_tw, F, c->hist_len, parts, p_off, nullptr, c->d_fade_env, fresh, fd_gt == carrier_gt ? job : gas_deferred_reduce(), nullptr, 0, 0, true, c->cfg.er_ring_frames, is_pk ? 0u : gr.count);
+					if (fd_gt == carrier_gt) {
+						carried_bytes = job.partials ? ((uint64_t)job.p_count + 1) * job.elems * sizeof(float) : 0;
+						job = gas_deferred_reduce();
+					}
+					break;
+				}
 				if (use_order && (c->cfg.flags & GAS_FLAG_DIRECTION_ORDER) != 0 && g_fd.n >= GAS_DIR_ORDER_MIN_SOURCES && (c->cfg.flags & GAS_FLAG_HRTF_CROSSFADE) == 0 && gas_dir_order_supported(c->tab.dirs)) {
 					const uint32_t seg = g_fd.n < GAS_DIR_ORDER_SEGMENT ? g_fd.n : GAS_DIR_ORDER_SEGMENT;
 					if (seg >= 2 * c->tab.dirs) {
@@ -734,7 +758,7 @@ int run_groups(gas_ctx *c, const gas_audio_frame *d_src, const uint32_t *d_slots
 				c->prof_bytes += group_bytes(c, gt + 1, groups[gt + 1].count) - group_bytes(c, gt + 1, 0);
 			}
 			c->prof_group = gt;
-			c->prof_uni = gt == G_FX_HRTF && uni_hrtf && groups[G_FX_HRTF_PK].count == 0;
+			c->prof_uni = (gt == G_FX_HRTF && uni_hrtf && groups[G_FX_HRTF_PK].count == 0) || ((gt == G_FX_ER_HRTF || gt == G_FX_ER_HRTF_PK) && uni_er);
 			c->prof_multi = false;
 			c->prof_pipe = (gt == G_3D_MIX || gt == G_3D_PROCESS || gt == G_FX_SHELF) && gas_biquad_uses_pipe(gt == G_FX_SHELF ? GAS_MODE_FX_HIGHSHELF : (force_mode >= 0 ? force_mode : (gt == G_3D_MIX ? GAS_MODE_MIX_CHANNEL : GAS_MODE_PROCESS_FRAMES)), gr.count, gt == G_3D_MIX ? channel_count : 1, F, false);
 		}

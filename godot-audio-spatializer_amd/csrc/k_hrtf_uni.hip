@@ -88,8 +88,16 @@ struct UniLds {
 // More than two buses (a playback reaches up to six, audio_spatializer.cpp:283-287): one launch per PAIR of buses --
 // bus_base names the pair (buses bus_base, bus_base + 1) and only the last launch commits the per-source state (history
 // row, previous gain, peak), so every pass transforms the same windows.
-template <int SQ, bool SRC_PCM, bool BUS2, int UW>
-__global__ __launch_bounds__(UW * 64, UW > 8 ? 3 : GAS_HRTF_WAVES_PER_SIMD) void k_hrtf_uni(gas_group_args g, const uint32_t *__restrict__ peak_bits, uint32_t peak_all, gas_dev_state st, gas_hrtf_table tab, const float2 *__restrict__ tw, float *__restrict__ partials, uint32_t p_offset, gas_cursor *__restrict__ cursors, const float *__restrict__ fade_env, const gas_params *__restrict__ fresh, gas_deferred_reduce job, const gas_bus_route *__restrict__ routes, uint32_t bus_rows, uint32_t bus_base, uint32_t commit, uint32_t nt_hist) {
+// ER (round 3): the chain [EARLY_REFLECTIONS, HRTF] in this kernel's shape -- the eight-tap gather of oracle
+// fx_early_reflections (y[i] = x[i] + sum_k g_k x[i - d_k], per-source ring of er_R frames) in front of the window, the
+// rest unchanged.  k_hrtf_ols<ER> (split frequency-domain / exact-peak workgroups, 22.5 us for cfg5) stays for the
+// cross-fade / direction-run forms; entries from peak_from on get their exact peak (the context's exact-peak group of
+// the chain rides behind its frequency-domain group in one list).  Measured and dropped: pulling the next source's ring
+// lines towards the L2 a trip ahead (one dword per 128-byte line) -- 24.6 us instead of 20.4: the tap reads are 64 of
+// the launch's 99 MB and already move at the rate a copy gets, the touches only add requests.
+template <int SQ, bool SRC_PCM, bool BUS2, int UW, bool ER = false>
+__global__ __launch_bounds__(UW * 64, UW > 8 ? 3 : GAS_HRTF_WAVES_PER_SIMD) void k_hrtf_uni(gas_group_args g, const uint32_t *__restrict__ peak_bits, uint32_t peak_all, gas_dev_state st, gas_hrtf_table tab, const float2 *__restrict__ tw, float *__restrict__ partials, uint32_t p_offset, gas_cursor *__restrict__ cursors, const float *__restrict__ fade_env, const gas_params *__restrict__ fresh, gas_deferred_reduce job, const gas_bus_route *__restrict__ routes, uint32_t bus_rows, uint32_t bus_base, uint32_t commit, uint32_t nt_hist, uint32_t er_R, uint32_t peak_from) {
+	static_assert(!ER || (!SRC_PCM && !BUS2 && UW == 8), "early reflections: float rows, one bus, eight waves");
 	constexpr bool LEAN = UniCfg<UW>::LEAN;
 	constexpr int UNI_SLICES = UniCfg<UW>::SLICES;
 	static_assert(!LEAN || (!SRC_PCM && !BUS2), "the twelve-wave form exists for float rows on one bus");
@@ -174,7 +182,7 @@ __global__ __launch_bounds__(UW * 64, UW > 8 ? 3 : GAS_HRTF_WAVES_PER_SIMD) void
 			lm.cur = cursors[lm.slot];
 		}
 		const uint32_t e = my_entry;
-		my_flag = peak_all ? 1u : (peak_bits ? (peak_bits[e >> 5] >> (e & 31)) & 1u : 0u);
+		my_flag = (peak_all || e >= peak_from) ? 1u : (peak_bits ? (peak_bits[e >> 5] >> (e & 31)) & 1u : 0u);
 		if (BUS2 && !commit) {
 			my_flag = 0; // the peak (of y, before any bus factor) is the committing pass's
 		}
@@ -395,6 +403,44 @@ __global__ __launch_bounds__(UW * 64, UW > 8 ? 3 : GAS_HRTF_WAVES_PER_SIMD) void
 				const float t = (lf + (float)(64 * q)) * (1.0f / (float)F);
 				xq[HQ + q] = mono * (m.g1 * t + (1 - t) * m.g0);
 			}
+		} else if constexpr (ER) {
+			// early reflections (oracle fx_early_reflections): this block into the ring, then per frame the taps in tap
+			// order, f32; 16 tap loads in flight per pass (more spill), results handed over through the wave's LDS slice
+			const gas_params *P = fresh ? fresh + m.row : st.params + m.slot; // device-published rows of this callback are not in the table yet
+			const gas_audio_frame *srow = g.src + (size_t)m.row * F;
+			const uint32_t er_pos = st.er_pos[m.slot];
+			gas_audio_frame *ring = st.er_ring + (size_t)m.slot * er_R;
+			float *xs = reinterpret_cast<float *>(lds);
+#pragma unroll
+			for (int q = 0; q < FQ; q++) { // unrolled (raw[] stays in registers), fenced into passes of two frames
+				if (q && q % 2 == 0) {
+					__builtin_amdgcn_sched_barrier(0);
+				}
+				const int f = lane + 64 * q;
+				const gas_audio_frame fr = raw[q];
+				ring[(er_pos + (uint32_t)f) & (er_R - 1)] = fr;
+				float yl = fr.left, yr = fr.right;
+#pragma unroll
+				for (int k = 0; k < GAS_ER_TAPS; k++) {
+					const uint32_t du = P->er_delay[k];
+					const int d = (int)(du < er_R - F ? du : er_R - F); // keeps every tap inside row / ring
+					const float gk = P->er_gain[k];
+					const int i = f - d;
+					const gas_audio_frame xp = i >= 0 ? srow[i] : ring[(er_pos + (uint32_t)(i + (int)er_R)) & (er_R - 1)];
+					yl = yl + gk * xp.left;
+					yr = yr + gk * xp.right;
+				}
+				xs[f] = (yl + yr) * 0.5f;
+			}
+			if (lane == 0) {
+				st.er_pos[m.slot] = (er_pos + F) & (er_R - 1);
+			}
+			wave_lds_sync();
+#pragma unroll
+			for (int q = 0; q < FQ; q++) {
+				xq[HQ + q] = xs[lane + 64 * q] * (m.g1 * tq[q] + omtq[q] * m.g0);
+			}
+			wave_lds_sync();
 		} else {
 #pragma unroll
 			for (int q = 0; q < FQ; q++) {
@@ -625,22 +671,24 @@ bool gas_hrtf_uni_twelve(uint32_t n, bool streams, bool buses) {
 	return !streams && !buses && mn != 0 && n >= mn && n >= wgs * UNI_W12 && n <= wgs * UNI_W12 * 64;
 }
 
-hipError_t gas_launch_hrtf_uni(hipStream_t stream, const gas_group_args &g, const uint32_t *peak_bits, bool peak_all, const gas_dev_state &st, const gas_hrtf_table &tab, const float2 *twiddles, uint32_t frames, uint32_t hist_len, float *partials, uint32_t p_offset, gas_cursor *cursors, const float *fade_env, const gas_params *fresh, const gas_deferred_reduce &job, const gas_bus_route *routes, uint32_t bus_rows, uint32_t bus_base, bool commit) {
+hipError_t gas_launch_hrtf_uni(hipStream_t stream, const gas_group_args &g, const uint32_t *peak_bits, bool peak_all, const gas_dev_state &st, const gas_hrtf_table &tab, const float2 *twiddles, uint32_t frames, uint32_t hist_len, float *partials, uint32_t p_offset, gas_cursor *cursors, const float *fade_env, const gas_params *fresh, const gas_deferred_reduce &job, const gas_bus_route *routes, uint32_t bus_rows, uint32_t bus_base, bool commit, uint32_t er_ring_frames, uint32_t peak_from) {
 	if (g.n == 0) {
 		return hipSuccess;
 	}
-	if (frames % 128 != 0 || frames > 512 || hist_len != 512 - frames / 2 || (routes && (cursors || g.order))) {
+	if (frames % 128 != 0 || frames > 512 || hist_len != 512 - frames / 2 || (routes && (cursors || g.order)) || (er_ring_frames && (routes || cursors || g.order))) {
 		return hipErrorInvalidValue;
 	}
 	const uint32_t wgs = gas_hrtf_uni_partials(g.n);
 	const uint32_t all = peak_all ? 1u : 0u;
-	const bool twelve = gas_hrtf_uni_twelve(g.n, cursors != nullptr, routes != nullptr);
+	const bool twelve = er_ring_frames == 0 && gas_hrtf_uni_twelve(g.n, cursors != nullptr, routes != nullptr);
 	const uint32_t nt_hist = g.n >= nt_hist_min_sources() ? 1u : 0u; // history rows larger than what stays cached between callbacks
 	const dim3 grid(wgs), block((twelve ? UNI_W12 : UNI_W) * 64);
-#define GAS_UNI_GO(SQv, PCM, BUS, W) hipLaunchKernelGGL((k_hrtf_uni<SQv, PCM, BUS, W>), grid, block, 0, stream, g, peak_bits, all, st, tab, twiddles, partials, p_offset, cursors, fade_env, fresh, job, routes, bus_rows, bus_base, commit ? 1u : 0u, nt_hist)
+#define GAS_UNI_GO(SQv, PCM, BUS, W) hipLaunchKernelGGL((k_hrtf_uni<SQv, PCM, BUS, W>), grid, block, 0, stream, g, peak_bits, all, st, tab, twiddles, partials, p_offset, cursors, fade_env, fresh, job, routes, bus_rows, bus_base, commit ? 1u : 0u, nt_hist, er_ring_frames, peak_from)
 #define GAS_UNI_CASE(SQv)                      \
 	case SQv:                                  \
-		if (routes) {                          \
+		if (er_ring_frames) {                  \
+			hipLaunchKernelGGL((k_hrtf_uni<SQv, false, false, 8, true>), grid, block, 0, stream, g, peak_bits, all, st, tab, twiddles, partials, p_offset, cursors, fade_env, fresh, job, routes, bus_rows, bus_base, commit ? 1u : 0u, nt_hist, er_ring_frames, peak_from); \
+		} else if (routes) {                   \
 			GAS_UNI_GO(SQv, false, true, 8);   \
 		} else if (cursors) {                  \
 			GAS_UNI_GO(SQv, true, false, 8);   \
