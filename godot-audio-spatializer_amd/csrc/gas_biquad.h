@@ -44,6 +44,18 @@ __device__ inline Coeffs highshelf_coeffs(float sampling_rate, float cutoff_hz, 
 	return c;
 }
 
+// [ENGINE] AudioFilterSW::Processor::process_one: one frame through the processor, the engine's operation order.  For
+// translation units that run with FMA contraction on elsewhere (k_hrtf_uni.hip): defined here, it keeps this file's
+// contract(off) when inlined.
+__device__ __forceinline__ float biquad_process_one(const Coeffs &co, float xi, float &a1, float &a2, float &b1, float &b2) {
+	const float yi = xi * co.b0 + b1 * co.b1 + b2 * co.b2 + a1 * co.a1 + a2 * co.a2;
+	a2 = a1;
+	b2 = b1;
+	b1 = xi;
+	a1 = yi;
+	return yi;
+}
+
 // [ENGINE] AudioFilterSW::prepare_coefficients for the other modes AudioEffectFilter's subclasses select (recollection
 // of servers/audio/audio_filter_sw.cpp, unpinned like the rest of SURVEY.md Appendix B): LOWPASS, HIGHPASS, BANDPASS
 // (Q doubled), NOTCH, LOWSHELF; one stage (FILTER_6DB).  Same shape as above: f64 arithmetic, members stored f32, then

@@ -55,6 +55,7 @@ struct Group {
 struct ChainRange {
 	uint16_t sig = 0;
 	uint32_t offset = 0, count = 0; // relative to the group's offset
+	bool peak_all = true, peak_any = true; // which of its sources report their exact peak (GAS_FLAG_PEAKS_DRAINING_ONLY; read by a last stage that is k_hrtf_uni)
 };
 
 constexpr uint32_t PROFILE_EVENTS = 4096;
@@ -122,7 +123,7 @@ struct gas_ctx {
 	gas_fx_settings *h_fx_upload = nullptr; // pinned, [max_sources], allocated by the first flush that needs it
 
 	// plain [HRTF] group of the cached list (k_hrtf_uni): which entries need their exact peak
-	uint32_t *h_peak_bits = nullptr, *d_peak_bits = nullptr; // [(max_sources + 31) / 32], bit k = entry k of the group
+	uint32_t *h_peak_bits = nullptr, *d_peak_bits = nullptr; // two halves of (max_sources + 31) / 32 words: bit k = entry k of the plain-[HRTF] group / of the staged group
 	bool uni_peak_all = false, uni_peak_any = false;
 	uint32_t *h_idx = nullptr; // pinned [2 * max_sources]: slots then rows, sorted by group
 	uint32_t *d_slots = nullptr, *d_rows = nullptr; // sorted by launch group
@@ -215,6 +216,7 @@ struct gas_ctx {
 	uint32_t prof_k = 1;
 	int prof_group = -1;
 	bool prof_uni = false; // the timed launch was k_hrtf_uni
+	bool uni_flt_enabled = getenv("GAS_UNI_FLT") == nullptr || atoi(getenv("GAS_UNI_FLT")) != 0; // [filter, HRTF] through k_hrtf_uni<FLT> (0: the filter stage and the HRTF stage as two launches, for comparison)
 	bool uni_er_enabled = getenv("GAS_UNI_ER") == nullptr || atoi(getenv("GAS_UNI_ER")) != 0; // [ER, HRTF] through k_hrtf_uni<ER> (0: k_hrtf_ols<ER>, the previous form, kept for comparison)
 	bool prof_pipe = false; // the timed launch was k_biquad_pipe
 	double ev_overhead_ms = 0.0; // marker/dispatch overhead of an event pair around one launch (calibrated)
@@ -707,6 +709,16 @@ int run_groups(gas_ctx *c, const gas_audio_frame *d_src, const uint32_t *d_slots
 					in.peaks = d_rows ? d_peaks : d_peaks + (size_t)off * 2;
 					const uint32_t *peak_rows = in.rows;
 					const bool last_is_uni = range_ends_in_uni(r, staged_uni);
+					const bool own = groups == c->groups; // the context's own list: GAS_FLAG_PEAKS_DRAINING_ONLY's bits exist
+					const int k0 = r.sig & 0xf;
+					if (last_is_uni && c->uni_flt_enabled && (r.sig >> 4) == GAS_FX_HRTF && (k0 == GAS_FX_HIGHSHELF || (k0 >= GAS_FX_LOWPASS && k0 <= GAS_FX_LOWSHELF)) && gas_shelf_scan_applies(k0 == GAS_FX_HIGHSHELF ? GAS_MODE_FX_HIGHSHELF : GAS_MODE_FX_FILTER, r.count, F)) {
+						// [one-biquad filter, HRTF]: one launch (k_hrtf_uni<FLT>), no rows in between.  The filter there is the
+						// scan form, so it is taken exactly where the two-launch road would take k_shelf_scan (same bits either
+						// way; small callbacks and GAS_SHELF_SCAN=0 keep the engine's serial order)
+						e = gas_launch_hrtf_uni(c->stream, in, own && r.peak_any && !r.peak_all ? c->d_peak_bits + (c->cfg.max_sources + 31) / 32 : nullptr, !own || r.peak_all, c->st, c->tab, c->d_tw, F, c->hist_len, parts, pp, nullptr, c->d_fade_env, nullptr, gas_deferred_reduce(), nullptr, 0, 0, true, 0, 0xffffffffu, r.offset, (uint32_t)k0, 0, c->cfg.mix_rate);
+						pp += range_partials(r, staged_uni);
+						continue;
+					}
 					for (int j = 0; j < 4 && e == hipSuccess; j++) {
 						const int kind = (r.sig >> (4 * j)) & 0xf;
 						if (!kind) {
@@ -715,7 +727,8 @@ int run_groups(gas_ctx *c, const gas_audio_frame *d_src, const uint32_t *d_slots
 						if (last_is_uni && kind == GAS_FX_HRTF) { // (the last effect: one HRTF per chain)
 							gas_group_args gu = in; // dense rows of the previous stage, peaks into the callback's rows
 							gu.peak_rows = peak_rows;
-							e = gas_launch_hrtf_uni(c->stream, gu, nullptr, true /* staged chains report exact peaks */, c->st, c->tab, c->d_tw, F, c->hist_len, parts, pp, nullptr, c->d_fade_env, nullptr);
+							// exact peaks for every source of the chain, or (GAS_FLAG_PEAKS_DRAINING_ONLY, the context's own list) for the draining ones
+							e = gas_launch_hrtf_uni(c->stream, gu, own && r.peak_any && !r.peak_all ? c->d_peak_bits + (c->cfg.max_sources + 31) / 32 : nullptr, !own || r.peak_all, c->st, c->tab, c->d_tw, F, c->hist_len, parts, pp, nullptr, c->d_fade_env, nullptr, gas_deferred_reduce(), nullptr, 0, 0, true, 0, 0xffffffffu, r.offset);
 							break;
 						}
 						gas_audio_frame *outb = c->d_chain[j & 1];
@@ -1158,6 +1171,29 @@ int build_groups(gas_ctx *c, const uint32_t *slots, uint32_t n) {
 			GAS_HIP(c, hipMemcpyAsync(c->d_peak_bits, c->h_peak_bits, (size_t)words * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
 		}
 	}
+	// staged chains whose last stage is k_hrtf_uni: the same rule (an HRTF source that is not draining reports +inf)
+	if (uni_ok(c) && (c->cfg.flags & GAS_FLAG_PEAKS_DRAINING_ONLY) != 0 && c->groups[G_FX_GENERIC].count > 0) {
+		const Group &gg = c->groups[G_FX_GENERIC];
+		const uint32_t half = (c->cfg.max_sources + 31) / 32, words = (gg.count + 31) / 32;
+		uint32_t *bits = c->h_peak_bits + half;
+		std::memset(bits, 0, (size_t)words * sizeof(uint32_t));
+		bool partial = false;
+		for (ChainRange &r : c->chain_ranges) {
+			uint32_t n_peak = 0;
+			for (uint32_t k = r.offset; k < r.offset + r.count; k++) {
+				if (wants_peak(c, c->slots[hs[gg.offset + k]])) {
+					bits[k >> 5] |= 1u << (k & 31);
+					n_peak++;
+				}
+			}
+			r.peak_any = n_peak > 0;
+			r.peak_all = n_peak == r.count;
+			partial = partial || (r.peak_any && !r.peak_all);
+		}
+		if (partial) {
+			GAS_HIP(c, hipMemcpyAsync(c->d_peak_bits + half, bits, (size_t)words * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+		}
+	}
 	if (n > 0) {
 		GAS_HIP(c, hipMemcpyAsync(c->d_slots, hs, (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
 		if (!c->cached_identity_rows) {
@@ -1385,8 +1421,8 @@ int gas_ctx_create(const gas_config *cfg, gas_ctx **out_ctx) {
 		GAS_HIP(c, hipHostMalloc(&c->h_upload, sizeof(gas_params) * N, hipHostMallocDefault));
 		GAS_HIP(c, hipHostMalloc(&c->h_upload_slots, sizeof(uint32_t) * N, hipHostMallocDefault));
 		GAS_HIP(c, hipHostMalloc(&c->h_idx, sizeof(uint32_t) * 2 * N, hipHostMallocDefault));
-		GAS_HIP(c, hipHostMalloc(&c->h_peak_bits, sizeof(uint32_t) * ((N + 31) / 32), hipHostMallocDefault));
-		GAS_HIP(c, hipMalloc(&c->d_peak_bits, sizeof(uint32_t) * ((N + 31) / 32)));
+		GAS_HIP(c, hipHostMalloc(&c->h_peak_bits, sizeof(uint32_t) * 2 * ((N + 31) / 32), hipHostMallocDefault));
+		GAS_HIP(c, hipMalloc(&c->d_peak_bits, sizeof(uint32_t) * 2 * ((N + 31) / 32)));
 		float2 h_tw[64 * 16];
 		gas_make_twiddles(h_tw);
 		GAS_HIP(c, hipMalloc(&c->d_tw, sizeof(h_tw)));

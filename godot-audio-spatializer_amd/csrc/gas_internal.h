@@ -163,7 +163,7 @@ struct gas_reduce_jobs {
 hipError_t gas_launch_mix_reduce_jobs(hipStream_t stream, const gas_reduce_jobs &jobs, uint32_t frames);
 bool gas_hrtf_multi_hist_in_lds(uint32_t n, uint32_t frames); // whether a launch over n sources keeps the history rows in LDS between its blocks
 hipError_t gas_launch_hrtf_multi(hipStream_t stream, const gas_group_args &g, const gas_hrtf_blocks &mb, const uint32_t *peak_bits, bool peak_all, const gas_dev_state &st, const gas_hrtf_table &tab, const float2 *twiddles, uint32_t frames, uint32_t hist_len, float *partials);
-hipError_t gas_launch_hrtf_uni(hipStream_t stream, const gas_group_args &g, const uint32_t *peak_bits, bool peak_all, const gas_dev_state &st, const gas_hrtf_table &tab, const float2 *twiddles, uint32_t frames, uint32_t hist_len, float *partials, uint32_t p_offset, gas_cursor *cursors, const float *fade_env, const gas_params *fresh, const gas_deferred_reduce &job = gas_deferred_reduce(), const gas_bus_route *routes = nullptr /* non-null: the two-bus form */, uint32_t bus_rows = 0, uint32_t bus_base = 0 /* the launch's pair of buses: bus_base, bus_base + 1 */, bool commit = true /* false: leave history / previous gain / peaks to a later pass */, uint32_t er_ring_frames = 0 /* non-zero: the chain [EARLY_REFLECTIONS, HRTF] */, uint32_t peak_from = 0xffffffffu /* entries from here on report their exact peak */);
+hipError_t gas_launch_hrtf_uni(hipStream_t stream, const gas_group_args &g, const uint32_t *peak_bits, bool peak_all, const gas_dev_state &st, const gas_hrtf_table &tab, const float2 *twiddles, uint32_t frames, uint32_t hist_len, float *partials, uint32_t p_offset, gas_cursor *cursors, const float *fade_env, const gas_params *fresh, const gas_deferred_reduce &job = gas_deferred_reduce(), const gas_bus_route *routes = nullptr /* non-null: the two-bus form */, uint32_t bus_rows = 0, uint32_t bus_base = 0 /* the launch's pair of buses: bus_base, bus_base + 1 */, bool commit = true /* false: leave history / previous gain / peaks to a later pass */, uint32_t er_ring_frames = 0 /* non-zero: the chain [EARLY_REFLECTIONS, HRTF] */, uint32_t peak_from = 0xffffffffu /* entries from here on report their exact peak */, uint32_t peak_bit_base = 0 /* entry e's bit in peak_bits is bit e + peak_bit_base */, uint32_t flt_kind = 0 /* non-zero: the chain [this one-biquad kind, HRTF] */, uint32_t flt_pos = 0 /* its chain position (processor state, effect settings) */, float mix_rate = 0.0f);
 hipError_t gas_launch_er_only(hipStream_t stream, const gas_group_args &g, const gas_dev_state &st, uint32_t frames, uint32_t er_ring_frames, float *partials, uint32_t p_offset, uint32_t p_stride, gas_audio_frame *rows_out = nullptr);
 // stages of a general effect chain (rows in -> rows out) and its final mix
 hipError_t gas_launch_hrtf_rows(hipStream_t stream, bool crossfade, const gas_group_args &g, const gas_dev_state &st, const gas_hrtf_table &tab, const float2 *twiddles, uint32_t frames, gas_audio_frame *rows_out);

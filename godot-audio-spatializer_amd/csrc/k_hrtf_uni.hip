@@ -33,6 +33,8 @@
 // found no effect on k_hrtf_ols, whose table was twice the size and whose launch was latency-bound elsewhere.)
 #define GAS_USE_NT 1
 #include "gas_hrtf_wave.h"
+#include "gas_biquad.h" // the engine's coefficient preparation (FLT): switches FMA contraction off for what follows ...
+#pragma clang fp contract(fast) // ... and this is the compiler's default for device code again (the transforms' bits do not change: checked against the ISA of the build before the include)
 
 #ifndef GAS_UNI12_DEFAULT_MIN
 #define GAS_UNI12_DEFAULT_MIN 0 // sources from which the twelve-wave form is the default (0 = only on request)
@@ -95,8 +97,21 @@ struct UniLds {
 // the chain rides behind its frequency-domain group in one list).  Measured and dropped: pulling the next source's ring
 // lines towards the L2 a trip ahead (one dword per 128-byte line) -- 24.6 us instead of 20.4: the tap reads are 64 of
 // the launch's 99 MB and already move at the rate a copy gets, the touches only add requests.
-template <int SQ, bool SRC_PCM, bool BUS2, int UW, bool ER = false>
-__global__ __launch_bounds__(UW * 64, UW > 8 ? 3 : GAS_HRTF_WAVES_PER_SIMD) void k_hrtf_uni(gas_group_args g, const uint32_t *__restrict__ peak_bits, uint32_t peak_all, gas_dev_state st, gas_hrtf_table tab, const float2 *__restrict__ tw, float *__restrict__ partials, uint32_t p_offset, gas_cursor *__restrict__ cursors, const float *__restrict__ fade_env, const gas_params *__restrict__ fresh, gas_deferred_reduce job, const gas_bus_route *__restrict__ routes, uint32_t bus_rows, uint32_t bus_base, uint32_t commit, uint32_t nt_hist, uint32_t er_R, uint32_t peak_from) {
+// FLT (round 3): the chain [one-biquad filter, HRTF] -- the reference example's high shelf in front of the HRTF
+// (examples/godot-gd-spatializer/gd_spatializer.gd:11-20), or any of the engine's other one-stage filters -- in this
+// kernel's shape instead of a filter launch that writes rows and an HRTF launch that reads them back (8192 sources:
+// 44 -> 31 us with every peak, 38 -> 23 with the draining ones; profiles/r03_notes.md).  The filter is k_shelf_scan's,
+// operation for operation (the same bits as the two-launch form): both ears, a lane owns F/64 consecutive frames (a
+// transpose through the wave's LDS slice on the way in and out), local response from rest, homogeneous solutions,
+// six-step affine scan over the lanes; a source whose poles lie outside r^2 <= 0.9 is walked serially by two lanes, one
+// per ear (the engine's form, bitwise k_biquad_mix's).  Filtering the MEAN of the ears instead (the HRTF's input; the
+// filter is linear) would halve the work, and was measured and dropped for its numerics: next to the unit circle the
+// mean's one extra rounding, or a per-ear walk from a mean history, is amplified ~1 / (1 - r) -- 1e-4 on a source's peak
+// for a 90 Hz high-pass.  Coefficients and history: prepared per LANE for the lane's own source in the prologue (one
+// f64 sin / cos per 64 sources), parked in LDS, read back wave-uniformly per trip.
+template <int SQ, bool SRC_PCM, bool BUS2, int UW, bool ER = false, bool FLT = false>
+__global__ __launch_bounds__(UW * 64, UW > 8 ? 3 : GAS_HRTF_WAVES_PER_SIMD) void k_hrtf_uni(gas_group_args g, const uint32_t *__restrict__ peak_bits, uint32_t peak_all, gas_dev_state st, gas_hrtf_table tab, const float2 *__restrict__ tw, float *__restrict__ partials, uint32_t p_offset, gas_cursor *__restrict__ cursors, const float *__restrict__ fade_env, const gas_params *__restrict__ fresh, gas_deferred_reduce job, const gas_bus_route *__restrict__ routes, uint32_t bus_rows, uint32_t bus_base, uint32_t commit, uint32_t nt_hist, uint32_t er_R, uint32_t peak_from, uint32_t peak_bit_base, uint32_t flt_kind, uint32_t flt_pos, float mix_rate) {
+	static_assert(!FLT || (!SRC_PCM && !BUS2 && UW == 8 && !ER), "filter in front: float rows, one bus, eight waves");
 	static_assert(!ER || (!SRC_PCM && !BUS2 && UW == 8), "early reflections: float rows, one bus, eight waves");
 	constexpr bool LEAN = UniCfg<UW>::LEAN;
 	constexpr int UNI_SLICES = UniCfg<UW>::SLICES;
@@ -110,6 +125,8 @@ __global__ __launch_bounds__(UW * 64, UW > 8 ? 3 : GAS_HRTF_WAVES_PER_SIMD) void
 	__shared__ float2 lds_all[UniLds<SQ, UW>::TOTAL_F2];
 	__shared__ float2 tw_lds[1024];
 	__shared__ float2 bus1_all[BUS2 ? UW * 2 * 512 : 1]; // bus 1: [wave][ear][512], the layout of the epilogue's fd
+	constexpr int FLT_W = 13; // b0 b1 b2 a1 a2, then the processor's ha1 ha2 hb1 hb2 of the left ear, of the right ear
+	__shared__ float flt_all[FLT ? UW * 64 * FLT_W : 1]; // FLT: [wave][source of the wave][FLT_W]
 	const int lane = threadIdx.x & 63;
 	const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 	float2 *lds = lds_all + wave * (UNI_SLICES * LDS_F2_HALF);
@@ -182,7 +199,7 @@ __global__ __launch_bounds__(UW * 64, UW > 8 ? 3 : GAS_HRTF_WAVES_PER_SIMD) void
 			lm.cur = cursors[lm.slot];
 		}
 		const uint32_t e = my_entry;
-		my_flag = (peak_all || e >= peak_from) ? 1u : (peak_bits ? (peak_bits[e >> 5] >> (e & 31)) & 1u : 0u);
+		my_flag = (peak_all || e >= peak_from) ? 1u : (peak_bits ? (peak_bits[(e + peak_bit_base) >> 5] >> ((e + peak_bit_base) & 31)) & 1u : 0u);
 		if (BUS2 && !commit) {
 			my_flag = 0; // the peak (of y, before any bus factor) is the committing pass's
 		}
@@ -190,6 +207,44 @@ __global__ __launch_bounds__(UW * 64, UW > 8 ? 3 : GAS_HRTF_WAVES_PER_SIMD) void
 	if constexpr (SRC_PCM) {
 		if (first < last) {
 			load_window<true, FQ>(g, bcast_meta<true>(lm, 0, F), lane, fade_env, raw); // needs the cursor
+		}
+	}
+	float *flt_par = flt_all + (FLT ? wave * 64 * FLT_W : 0);
+	if constexpr (FLT) {
+		if (have) {
+			Coeffs co;
+			if (flt_kind == GAS_FX_HIGHSHELF) {
+				const gas_params *P = st.params + lm.slot;
+				co = highshelf_coeffs(mix_rate, P->fx_shelf_cutoff_hz, P->fx_shelf_gain);
+			} else {
+				const gas_fx_settings *S = st.fxs + lm.slot;
+				co = filter_coeffs((int)flt_kind, mix_rate, S->filter_cutoff_hz[flt_pos], S->filter_resonance[flt_pos], S->filter_gain[flt_pos]);
+			}
+			float *bq = st.bq;
+			const size_t bs = st.bq_stride, s0 = ((size_t)lm.slot * 4 + flt_pos) * 2;
+			float *my = flt_par + lane * FLT_W;
+			my[0] = co.b0;
+			my[1] = co.b1;
+			my[2] = co.b2;
+			my[3] = co.a1;
+			my[4] = co.a2;
+#pragma unroll
+			for (int ear = 0; ear < 2; ear++) {
+				my[5 + 4 * ear] = bq[BQ_HA1 * bs + s0 + ear];
+				my[6 + 4 * ear] = bq[BQ_HA2 * bs + s0 + ear];
+				my[7 + 4 * ear] = bq[BQ_HB1 * bs + s0 + ear];
+				my[8 + 4 * ear] = bq[BQ_HB2 * bs + s0 + ear];
+			}
+			if (commit) { // the snapped coefficients are part of the processor too (k_biquad_mix stores them)
+#pragma unroll
+				for (int ear = 0; ear < 2; ear++) {
+					bq[BQ_B0 * bs + s0 + ear] = co.b0;
+					bq[BQ_B1 * bs + s0 + ear] = co.b1;
+					bq[BQ_B2 * bs + s0 + ear] = co.b2;
+					bq[BQ_A1 * bs + s0 + ear] = co.a1;
+					bq[BQ_A2 * bs + s0 + ear] = co.a2;
+				}
+			}
 		}
 	}
 	// LEAN: the stored half of source i's HRIR row, global -> LDS slot (i & 1), 4 x 1 KiB, no VGPR landing set
@@ -441,6 +496,132 @@ __global__ __launch_bounds__(UW * 64, UW > 8 ? 3 : GAS_HRTF_WAVES_PER_SIMD) void
 				xq[HQ + q] = xs[lane + 64 * q] * (m.g1 * tq[q] + omtq[q] * m.g0);
 			}
 			wave_lds_sync();
+		} else if constexpr (FLT) {
+			constexpr int P = FQ; // consecutive frames per lane in the filter's layout
+			const float *hp = flt_par + (e - first) * FLT_W; // wave-uniform address (written before the prologue's barrier)
+			Coeffs co;
+			co.b0 = hp[0];
+			co.b1 = hp[1];
+			co.b2 = hp[2];
+			co.a1 = hp[3];
+			co.a2 = hp[4];
+			float2 *xs = lds; // the block's frames, both ears
+			float *bq = st.bq;
+			const size_t bs = st.bq_stride, s0 = ((size_t)m.slot * 4 + flt_pos) * 2;
+#pragma unroll
+			for (int q = 0; q < FQ; q++) {
+				xs[lane + 64 * q] = make_float2(raw[q].left, raw[q].right);
+			}
+			wave_lds_sync();
+			const bool serial = !(fabsf(__int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(co.a2)))) <= 0.9f); // wave-uniform; NaN goes serial too
+			if (serial) {
+				if (lane < 2) { // each ear on its own lane, [ENGINE] process_one's operation order, no contraction
+					float a1 = hp[5 + 4 * lane], a2 = hp[6 + 4 * lane], b1 = hp[7 + 4 * lane], b2 = hp[8 + 4 * lane];
+					float *sr = reinterpret_cast<float *>(xs);
+					for (uint32_t i = 0; i < F; i++) {
+						sr[2 * i + lane] = biquad_process_one(co, sr[2 * i + lane], a1, a2, b1, b2);
+					}
+					bq[BQ_HA1 * bs + s0 + lane] = a1;
+					bq[BQ_HA2 * bs + s0 + lane] = a2;
+					bq[BQ_HB1 * bs + s0 + lane] = b1;
+					bq[BQ_HB2 * bs + s0 + lane] = b2;
+				}
+			} else {
+				float x[2][P], y[2][P], p[P], q2[P];
+#pragma unroll
+				for (int k = 0; k < P; k++) {
+					const float2 v = xs[lane * P + k];
+					x[0][k] = v.x;
+					x[1][k] = v.y;
+				}
+				// homogeneous solutions p (state (1, 0)) and q (state (0, 1)): the same in every lane and for both ears
+				p[0] = co.a1;
+				q2[0] = co.a2;
+				p[1] = __builtin_fmaf(co.a1, p[0], co.a2);
+				q2[1] = __fmul_rn(co.a1, q2[0]);
+#pragma unroll
+				for (int k = 2; k < P; k++) {
+					p[k] = __builtin_fmaf(co.a1, p[k - 1], __fmul_rn(co.a2, p[k - 2]));
+					q2[k] = __builtin_fmaf(co.a1, q2[k - 1], __fmul_rn(co.a2, q2[k - 2]));
+				}
+				float sx[2], sy[2]; // the state leaving this lane, per ear
+#pragma unroll
+				for (int ear = 0; ear < 2; ear++) {
+					const float ha1 = hp[5 + 4 * ear], ha2 = hp[6 + 4 * ear];
+					float xm1 = __shfl_up(x[ear][P - 1], 1, 64), xm2 = __shfl_up(x[ear][P - 2], 1, 64);
+					if (lane == 0) {
+						xm1 = hp[7 + 4 * ear];
+						xm2 = hp[8 + 4 * ear];
+					}
+					float w1 = 0.0f, w2 = 0.0f;
+#pragma unroll
+					for (int k = 0; k < P; k++) {
+						const float xa = k >= 1 ? x[ear][k - 1] : xm1;
+						const float xb = k >= 2 ? x[ear][k - 2] : (k == 1 ? xm1 : xm2);
+						const float u = __builtin_fmaf(co.b2, xb, __builtin_fmaf(co.b1, xa, __fmul_rn(co.b0, x[ear][k])));
+						const float w = __builtin_fmaf(co.a2, w2, __builtin_fmaf(co.a1, w1, u));
+						y[ear][k] = w;
+						w2 = w1;
+						w1 = w;
+					}
+					sx[ear] = y[ear][P - 1];
+					sy[ear] = y[ear][P - 2];
+					if (lane == 0) { // the processor's history enters through lane 0
+						sx[ear] = __builtin_fmaf(p[P - 1], ha1, __builtin_fmaf(q2[P - 1], ha2, sx[ear]));
+						sy[ear] = __builtin_fmaf(p[P - 2], ha1, __builtin_fmaf(q2[P - 2], ha2, sy[ear]));
+					}
+				}
+				float m00 = p[P - 1], m01 = q2[P - 1], m10 = p[P - 2], m11 = q2[P - 2];
+#pragma unroll
+				for (int d = 1; d < 64; d *= 2) { // inclusive scan of s_l = M s_(l-1) + c_l: distances 1, 2, 4, ... with M, M^2, M^4, ...
+#pragma unroll
+					for (int ear = 0; ear < 2; ear++) {
+						const float ox = __shfl_up(sx[ear], d, 64), oy = __shfl_up(sy[ear], d, 64);
+						if (lane >= d) {
+							sx[ear] = __builtin_fmaf(m00, ox, __builtin_fmaf(m01, oy, sx[ear]));
+							sy[ear] = __builtin_fmaf(m10, ox, __builtin_fmaf(m11, oy, sy[ear]));
+						}
+					}
+					const float n00 = __builtin_fmaf(m00, m00, __fmul_rn(m01, m10)), n01 = __builtin_fmaf(m00, m01, __fmul_rn(m01, m11));
+					const float n10 = __builtin_fmaf(m10, m00, __fmul_rn(m11, m10)), n11 = __builtin_fmaf(m10, m01, __fmul_rn(m11, m11));
+					m00 = n00;
+					m01 = n01;
+					m10 = n10;
+					m11 = n11;
+				}
+#pragma unroll
+				for (int ear = 0; ear < 2; ear++) {
+					float ix = __shfl_up(sx[ear], 1, 64), iy = __shfl_up(sy[ear], 1, 64); // the state entering this lane
+					if (lane == 0) {
+						ix = hp[5 + 4 * ear];
+						iy = hp[6 + 4 * ear];
+					}
+#pragma unroll
+					for (int k = 0; k < P; k++) {
+						y[ear][k] = __builtin_fmaf(p[k], ix, __builtin_fmaf(q2[k], iy, y[ear][k]));
+					}
+				}
+#pragma unroll
+				for (int k = 0; k < P; k++) {
+					xs[lane * P + k] = make_float2(y[0][k], y[1][k]);
+				}
+				if (lane == 63) { // the processor after the block: last two outputs, last two inputs
+#pragma unroll
+					for (int ear = 0; ear < 2; ear++) {
+						bq[BQ_HA1 * bs + s0 + ear] = y[ear][P - 1];
+						bq[BQ_HA2 * bs + s0 + ear] = y[ear][P - 2];
+						bq[BQ_HB1 * bs + s0 + ear] = x[ear][P - 1];
+						bq[BQ_HB2 * bs + s0 + ear] = x[ear][P - 2];
+					}
+				}
+			}
+			wave_lds_sync();
+#pragma unroll
+			for (int q = 0; q < FQ; q++) {
+				const float2 yy = xs[lane + 64 * q];
+				xq[HQ + q] = ((yy.x + yy.y) * 0.5f) * (m.g1 * tq[q] + omtq[q] * m.g0);
+			}
+			wave_lds_sync();
 		} else {
 #pragma unroll
 			for (int q = 0; q < FQ; q++) {
@@ -671,23 +852,25 @@ bool gas_hrtf_uni_twelve(uint32_t n, bool streams, bool buses) {
 	return !streams && !buses && mn != 0 && n >= mn && n >= wgs * UNI_W12 && n <= wgs * UNI_W12 * 64;
 }
 
-hipError_t gas_launch_hrtf_uni(hipStream_t stream, const gas_group_args &g, const uint32_t *peak_bits, bool peak_all, const gas_dev_state &st, const gas_hrtf_table &tab, const float2 *twiddles, uint32_t frames, uint32_t hist_len, float *partials, uint32_t p_offset, gas_cursor *cursors, const float *fade_env, const gas_params *fresh, const gas_deferred_reduce &job, const gas_bus_route *routes, uint32_t bus_rows, uint32_t bus_base, bool commit, uint32_t er_ring_frames, uint32_t peak_from) {
+hipError_t gas_launch_hrtf_uni(hipStream_t stream, const gas_group_args &g, const uint32_t *peak_bits, bool peak_all, const gas_dev_state &st, const gas_hrtf_table &tab, const float2 *twiddles, uint32_t frames, uint32_t hist_len, float *partials, uint32_t p_offset, gas_cursor *cursors, const float *fade_env, const gas_params *fresh, const gas_deferred_reduce &job, const gas_bus_route *routes, uint32_t bus_rows, uint32_t bus_base, bool commit, uint32_t er_ring_frames, uint32_t peak_from, uint32_t peak_bit_base, uint32_t flt_kind, uint32_t flt_pos, float mix_rate) {
 	if (g.n == 0) {
 		return hipSuccess;
 	}
-	if (frames % 128 != 0 || frames > 512 || hist_len != 512 - frames / 2 || (routes && (cursors || g.order)) || (er_ring_frames && (routes || cursors || g.order))) {
+	if (frames % 128 != 0 || frames > 512 || hist_len != 512 - frames / 2 || (routes && (cursors || g.order)) || ((er_ring_frames || flt_kind) && (routes || cursors || g.order)) || (er_ring_frames && flt_kind)) {
 		return hipErrorInvalidValue;
 	}
 	const uint32_t wgs = gas_hrtf_uni_partials(g.n);
 	const uint32_t all = peak_all ? 1u : 0u;
-	const bool twelve = er_ring_frames == 0 && gas_hrtf_uni_twelve(g.n, cursors != nullptr, routes != nullptr);
+	const bool twelve = er_ring_frames == 0 && flt_kind == 0 && gas_hrtf_uni_twelve(g.n, cursors != nullptr, routes != nullptr);
 	const uint32_t nt_hist = g.n >= nt_hist_min_sources() ? 1u : 0u; // history rows larger than what stays cached between callbacks
 	const dim3 grid(wgs), block((twelve ? UNI_W12 : UNI_W) * 64);
-#define GAS_UNI_GO(SQv, PCM, BUS, W) hipLaunchKernelGGL((k_hrtf_uni<SQv, PCM, BUS, W>), grid, block, 0, stream, g, peak_bits, all, st, tab, twiddles, partials, p_offset, cursors, fade_env, fresh, job, routes, bus_rows, bus_base, commit ? 1u : 0u, nt_hist, er_ring_frames, peak_from)
+#define GAS_UNI_GO(SQv, PCM, BUS, W) hipLaunchKernelGGL((k_hrtf_uni<SQv, PCM, BUS, W>), grid, block, 0, stream, g, peak_bits, all, st, tab, twiddles, partials, p_offset, cursors, fade_env, fresh, job, routes, bus_rows, bus_base, commit ? 1u : 0u, nt_hist, er_ring_frames, peak_from, peak_bit_base, flt_kind, flt_pos, mix_rate)
 #define GAS_UNI_CASE(SQv)                      \
 	case SQv:                                  \
-		if (er_ring_frames) {                  \
-			hipLaunchKernelGGL((k_hrtf_uni<SQv, false, false, 8, true>), grid, block, 0, stream, g, peak_bits, all, st, tab, twiddles, partials, p_offset, cursors, fade_env, fresh, job, routes, bus_rows, bus_base, commit ? 1u : 0u, nt_hist, er_ring_frames, peak_from); \
+		if (flt_kind) {                        \
+			hipLaunchKernelGGL((k_hrtf_uni<SQv, false, false, 8, false, true>), grid, block, 0, stream, g, peak_bits, all, st, tab, twiddles, partials, p_offset, cursors, fade_env, fresh, job, routes, bus_rows, bus_base, commit ? 1u : 0u, nt_hist, er_ring_frames, peak_from, peak_bit_base, flt_kind, flt_pos, mix_rate); \
+		} else if (er_ring_frames) {           \
+			hipLaunchKernelGGL((k_hrtf_uni<SQv, false, false, 8, true>), grid, block, 0, stream, g, peak_bits, all, st, tab, twiddles, partials, p_offset, cursors, fade_env, fresh, job, routes, bus_rows, bus_base, commit ? 1u : 0u, nt_hist, er_ring_frames, peak_from, peak_bit_base, flt_kind, flt_pos, mix_rate); \
 		} else if (routes) {                   \
 			GAS_UNI_GO(SQv, false, true, 8);   \
 		} else if (cursors) {                  \

@@ -111,7 +111,9 @@ typedef struct gas_config {
  * (audio_spatializer.cpp:464-469).  With this flag HRTF sources that are NOT marked draining are summed
  * in the frequency domain (one forward FFT per source, inverse FFTs per workgroup) and report
  * peak = +inf ("not measured", never passes the gate); the mix is unchanged.  Without it every source
- * reports its exact peak, as the reference computes it. */
+ * reports its exact peak, as the reference computes it.  "HRTF sources": chains [HRTF] and [ER, HRTF], and any other
+ * chain whose LAST effect is the HRTF when the context runs that stage in the one-launch kernel (no cross-fade /
+ * direction-run flags); every other chain reports exact peaks with or without the flag (they cost nothing there). */
 #define GAS_FLAG_PEAKS_DRAINING_ONLY 1u
 /* NEW: when an HRTF source's direction differs from the one of its previous callback, render the
  * block with both HRIRs and blend old -> new with t = i/F (the analogue of the per-block volume lerp,

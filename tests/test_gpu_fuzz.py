@@ -43,7 +43,11 @@ def test_random_configuration(gas, ob, seed):
     draining = rng.random(n) < float(rng.choice([0.0, 0.1, 1.0]))
     for s in slots[draining]:
         ctx.source_set_draining(s, True)
-    exact = draining | (not (flags & K.FLAG_PEAKS_DRAINING_ONLY)) | (not fused_hrtf)
+    # which chains leave a non-draining source's peak unmeasured under GAS_FLAG_PEAKS_DRAINING_ONLY: the fused HRTF chains,
+    # and staged chains whose last stage is the one-launch HRTF kernel (no cross-fade / direction-run flags)
+    one_launch = not (flags & (K.FLAG_HRTF_CROSSFADE | K.FLAG_DIRECTION_RUNS | K.FLAG_DIRECTION_ORDER))
+    skips_peaks = fused_hrtf or (one_launch and len(chain) >= 2 and chain[-1] == HRTF)
+    exact = draining | (not (flags & K.FLAG_PEAKS_DRAINING_ONLY)) | (not skips_peaks)
     p = None
     for b in range(5):
         if b == 0 or rng.random() < 0.6:

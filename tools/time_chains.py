@@ -12,10 +12,10 @@ from godot_audio_spatializer_amd import synth  # noqa: E402
 HS, ER, HRTF = 1, 2, 3
 
 
-def run(chain, n, frames=512, steps=300):
+def run(chain, n, frames=512, steps=300, flags=0):
     rng = np.random.default_rng(0)
     ring = 4096 if ER in chain else 0
-    ctx = gas.SpatializerContext(max_sources=n, frames=frames, er_ring_frames=ring)
+    ctx = gas.SpatializerContext(max_sources=n, frames=frames, er_ring_frames=ring, flags=flags)
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
     ctx.hrtf_load(synth.synthetic_hrir(rng, dirs=1024))
     slots = ctx.source_alloc_many(n, gas.capi.KIND_EFFECT, chain)
@@ -34,7 +34,7 @@ def run(chain, n, frames=512, steps=300):
     e1.record()
     torch.cuda.synchronize()
     us = 1e3 * e0.elapsed_time(e1) / steps
-    print(f"chain {str(chain):14s} n={n:6d} F={frames}: {us:7.1f} us/callback")
+    print(f"chain {str(chain):14s} n={n:6d} F={frames} flags={flags}: {us:7.1f} us/callback")
     ctx.close()
 
 
@@ -42,3 +42,5 @@ if __name__ == "__main__":
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
     for chain in ((HRTF,), (HS, HRTF), (HRTF, HS), (HS,), (HS, HS), (ER, HRTF), (HS, ER, HRTF), (ER, HS)):
         run(chain, n, 256 if ER in chain else 512)
+    for chain in ((HRTF,), (HS, HRTF), (ER, HRTF), (HS, ER, HRTF)):  # peaks of draining sources only (none is draining here)
+        run(chain, n, 256 if ER in chain else 512, flags=gas.capi.FLAG_PEAKS_DRAINING_ONLY)
