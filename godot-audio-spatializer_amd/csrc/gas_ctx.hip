@@ -724,6 +724,13 @@ int run_groups(gas_ctx *c, const gas_audio_frame *d_src, const uint32_t *d_slots
 						if (!kind) {
 							break;
 						}
+						if (last_is_uni && c->uni_er_enabled && kind == GAS_FX_EARLY_REFLECTIONS && j < 3 && ((r.sig >> (4 * (j + 1))) & 0xf) == GAS_FX_HRTF) {
+							// ... [ER, HRTF] at the end of a longer chain: both in the last launch (k_hrtf_uni<ER>), no rows in between
+							gas_group_args gu = in;
+							gu.peak_rows = peak_rows;
+							e = gas_launch_hrtf_uni(c->stream, gu, own && r.peak_any && !r.peak_all ? c->d_peak_bits + (c->cfg.max_sources + 31) / 32 : nullptr, !own || r.peak_all, c->st, c->tab, c->d_tw, F, c->hist_len, parts, pp, nullptr, c->d_fade_env, nullptr, gas_deferred_reduce(), nullptr, 0, 0, true, c->cfg.er_ring_frames, 0xffffffffu, r.offset);
+							break;
+						}
 						if (last_is_uni && kind == GAS_FX_HRTF) { // (the last effect: one HRTF per chain)
 							gas_group_args gu = in; // dense rows of the previous stage, peaks into the callback's rows
 							gu.peak_rows = peak_rows;
