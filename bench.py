@@ -692,6 +692,46 @@ def main():
                 result["in_process_multi"] = {"what": "gas_multi_process_block_mem(GAS_MEM_DEVICE), G contexts sharing cuda:0, 8192 sources in total, a device-resident publish every 2nd callback, every callback gathered and summed on the root (no bucket); compare with ordered.ms_per_step (one context, same sources)", "runs": [in_process_multi(env, [local_rank] * G, n_local // G, callbacks=200) for G in (2, 8)]}
                 for r_ in result["in_process_multi"]["runs"]:
                     r_["added_us_vs_one_context"] = (r_["ms_per_step"] - result["ordered"]["ms_per_step"]) * 1e3
+            if args.workload == "hrtf" and n_local == 8192:
+                # the chains either side of the headline's -- [HIGHSHELF, HRTF] (the reference example's shelf in
+                # front of the HRTF, examples/godot-gd-spatializer/gd_spatializer.gd:11-20) and cfg5's [ER, HRTF] -- as
+                # synchronous callbacks, one-launch form vs the form it replaced (environment switches read at context creation)
+                def chain_us(chain_, n_, frames_, ring_, env_key, env_val):
+                    old = os.environ.get(env_key)
+                    os.environ[env_key] = env_val
+                    try:
+                        cctx = gas.SpatializerContext(max_sources=n_, frames=frames_, er_ring_frames=ring_, flags=K.FLAG_PEAKS_DRAINING_ONLY, device=local_rank)
+                    finally:
+                        if old is None:
+                            del os.environ[env_key]
+                        else:
+                            os.environ[env_key] = old
+                    cctx.set_stream(torch.cuda.current_stream().cuda_stream)
+                    cctx.hrtf_load(hrir)
+                    sl_ = cctx.source_alloc_many(n_, K.KIND_EFFECT, chain_)
+                    cctx.params_publish_batch(sl_, synth.draw_params(np.random.default_rng(12), n_, dirs=args.dirs, ring_frames=max(ring_, 2 * frames_), frames=frames_))
+                    c_src = torch.rand(n_, frames_, 2, device="cuda") - 0.5
+                    c_out = torch.zeros(1, frames_, 2, device="cuda")
+                    c_pk = torch.zeros(n_, 2, device="cuda")
+                    for i_ in range(10):
+                        cctx.process_block_raw(c_src.data_ptr(), sl_ if i_ == 0 else None, n_, frames_, c_out.data_ptr(), c_pk.data_ptr(), 1)
+                    torch.cuda.synchronize()
+                    e0_, e1_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0_.record()
+                    for _ in range(200):
+                        cctx.process_block_raw(c_src.data_ptr(), None, n_, frames_, c_out.data_ptr(), c_pk.data_ptr(), 1)
+                    e1_.record()
+                    torch.cuda.synchronize()
+                    cctx.close()
+                    return 1e3 * e0_.elapsed_time(e1_) / 200
+
+                result["chains"] = {
+                    "what": "ordered callbacks (one DSP launch + k_mix_reduce, GPU timeline, 200 callbacks), GAS_FLAG_PEAKS_DRAINING_ONLY, no playback draining; us per callback",
+                    "runs": [
+                        {"chain": "[HIGHSHELF, HRTF]", "sources": 8192, "frames": 512, "one_launch_us": chain_us((1, 3), 8192, 512, 0, "GAS_UNI_FLT", "1"), "two_launch_us": chain_us((1, 3), 8192, 512, 0, "GAS_UNI_FLT", "0"), "kernels": "k_hrtf_uni<FLT> vs k_shelf_scan + k_hrtf_uni"},
+                        {"chain": "[HIGHSHELF, ER, HRTF]", "sources": 8192, "frames": 256, "one_launch_us": chain_us((1, 2, 3), 8192, 256, 4096, "GAS_UNI_ER", "1"), "two_launch_us": chain_us((1, 2, 3), 8192, 256, 4096, "GAS_UNI_ER", "0"), "kernels": "k_shelf_scan + k_hrtf_uni<ER> vs k_shelf_scan + k_er_only + k_hrtf_uni (the chain's last two effects in one launch or two)"},
+                    ],
+                }
         except Exception as e:  # the extras must never cost the headline line
             result["extras_error"] = repr(e)
     env["srcs"].clear()

@@ -217,7 +217,14 @@ struct gas_ctx {
 	int prof_group = -1;
 	bool prof_uni = false; // the timed launch was k_hrtf_uni
 	bool uni_flt_enabled = getenv("GAS_UNI_FLT") == nullptr || atoi(getenv("GAS_UNI_FLT")) != 0; // [filter, HRTF] through k_hrtf_uni<FLT> (0: the filter stage and the HRTF stage as two launches, for comparison)
-	bool uni_er_enabled = getenv("GAS_UNI_ER") == nullptr || atoi(getenv("GAS_UNI_ER")) != 0; // [ER, HRTF] through k_hrtf_uni<ER> (0: k_hrtf_ols<ER>, the previous form, kept for comparison)
+	// [ER, HRTF] through k_hrtf_uni<ER>.  GAS_UNI_ER = 1 (default): when at most a quarter of the callback's playbacks want
+	// their exact peak.  In throughput mode it is the faster form (the launch carries the previous callback's sum, which
+	// k_hrtf_ols<ER> has no registers to park: 20.4 vs 22.4 us for cfg5), an ordered callback is a tie (22.7 / 22.4 us) --
+	// the choice does not look at the mode, so the two modes stay bit-identical -- and with every peak exact the split
+	// kernel's exact-peak workgroups win (23.6 vs 25.8 us).  0: never.  2: always (tests, A/B).  Staged chains that END in
+	// [ER, HRTF] take it whenever it is not 0 (one launch less, no rows in between).
+	int uni_er_mode = getenv("GAS_UNI_ER") ? atoi(getenv("GAS_UNI_ER")) : 1;
+	bool uni_er_enabled = uni_er_mode != 0;
 	bool prof_pipe = false; // the timed launch was k_biquad_pipe
 	double ev_overhead_ms = 0.0; // marker/dispatch overhead of an event pair around one launch (calibrated)
 	uint32_t prof_every = 1, prof_tick = 0; // bracket every Nth callback's dominant launch
@@ -483,7 +490,9 @@ int run_groups(gas_ctx *c, const gas_audio_frame *d_src, const uint32_t *d_slots
 	const bool staged_uni = uni_ok(c) && c->run_buses == nullptr && gas_hrtf_uni_waves() == 8; // staged chains ending in the HRTF: last stage = k_hrtf_uni
 	// [ER, HRTF] through k_hrtf_uni<ER> (22.5 -> see profiles/r03_notes.md): the exact-peak group's entries follow the
 	// frequency-domain group's in the callback's list, so one launch covers both
-	const bool uni_er = uni_ok(c) && c->run_buses == nullptr && gas_hrtf_uni_waves() == 8 && c->uni_er_enabled && (groups[G_FX_ER_HRTF].count == 0 || groups[G_FX_ER_HRTF_PK].count == 0 || groups[G_FX_ER_HRTF].offset + groups[G_FX_ER_HRTF].count == groups[G_FX_ER_HRTF_PK].offset);
+	pipelined = pipelined && c->pipelined_mix && channel_count == 1 && c->cfg.channel_count == 1;
+	const bool uni_er_pays = c->uni_er_mode == 2 || groups[G_FX_ER_HRTF_PK].count * 4 <= groups[G_FX_ER_HRTF].count + groups[G_FX_ER_HRTF_PK].count;
+	const bool uni_er = uni_ok(c) && c->run_buses == nullptr && gas_hrtf_uni_waves() == 8 && c->uni_er_enabled && uni_er_pays && (groups[G_FX_ER_HRTF].count == 0 || groups[G_FX_ER_HRTF_PK].count == 0 || groups[G_FX_ER_HRTF].offset + groups[G_FX_ER_HRTF].count == groups[G_FX_ER_HRTF_PK].offset);
 	plan_partials(groups, ranges, pcount, uni_hrtf, staged_uni, uni_er);
 	uint32_t p_total = 0, p_mix = 0;
 	for (int gt = 0; gt < G_COUNT; gt++) {
@@ -508,7 +517,6 @@ int run_groups(gas_ctx *c, const gas_audio_frame *d_src, const uint32_t *d_slots
 	if (carrier_gt >= 0) {
 		carrier = (pcount[carrier_gt] + pcount[carrier_gt + 1]) * GAS_HRTF_JOB_WAVES >= F * 2 / 4 && c->pending_mix.p_total <= 256;
 	}
-	pipelined = pipelined && c->pipelined_mix && channel_count == 1 && c->cfg.channel_count == 1;
 	int rc = GAS_OK;
 	if (!c->pending_more.empty()) { // left by a batched launch: a single launch carries one sum only
 		const std::vector<gas_ctx::PendingMix> more = std::move(c->pending_more);

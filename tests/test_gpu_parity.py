@@ -107,10 +107,10 @@ def test_er_hrtf_cfg5(gas, ob):
     run_pair(gas, ob, gas.capi.KIND_EFFECT, (gas.capi.FX_EARLY_REFLECTIONS, gas.capi.FX_HRTF), 90, 256, 20, hrir=hrir, ring=4096, redraw_every=3)
 
 
-@pytest.mark.parametrize("uni_er", ["1", "0"])
+@pytest.mark.parametrize("uni_er", ["2", "0"])
 def test_er_hrtf_both_kernels_many_sources_per_wave(gas, ob, monkeypatch, uni_er):
-    """[ER, HRTF] through k_hrtf_uni<ER> (the default) and through k_hrtf_ols<ER> (GAS_UNI_ER=0, read when the context is
-    made), at a size where a wave handles several sources in sequence; exact peaks only for the draining sixth, so the
+    """[ER, HRTF] through k_hrtf_uni<ER> (GAS_UNI_ER=2: always; by default when at most a quarter of the playbacks
+    want their exact peak) and through k_hrtf_ols<ER> (GAS_UNI_ER=0; read when the context is made), at a size where a wave handles several sources in sequence; exact peaks only for the draining sixth, so the
     launch carries the frequency-domain group and the exact-peak group behind it (peak_from)."""
     from godot_audio_spatializer_amd import synth
 
