@@ -271,6 +271,18 @@ def test_filter_stage_as_a_scan_matches_oracle(gas, ob, chain, frames, monkeypat
             np.testing.assert_array_equal(p1, p0)
 
 
+@pytest.mark.parametrize("frames", [128, 256, 384])
+@pytest.mark.parametrize("chain", [(HS, HRTF), (BP, HRTF), (HS, ER, HRTF)])
+def test_one_launch_chain_tails_at_every_block_size(gas, ob, chain, frames):
+    """k_hrtf_uni<FLT> ([filter, HRTF]) and k_hrtf_uni<ER> behind a filter stage ([.., ER, HRTF]) at the block sizes the
+    other tests leave out, 2600 playbacks (waves with one and with two sources), a sixth of them draining under
+    GAS_FLAG_PEAKS_DRAINING_ONLY."""
+    from test_gpu_parity import run_pair
+
+    ring = 2048 if ER in chain else 0
+    run_pair(gas, ob, gas.capi.KIND_EFFECT, chain, 2600, frames, 4, hrir=_hrir(), ring=ring, dirs=32, redraw_every=2, flags=gas.capi.FLAG_PEAKS_DRAINING_ONLY, draining_every=6)
+
+
 def test_scan_forms_after_a_switch_to_an_ill_conditioned_filter(gas, ob, monkeypatch):
     """What the scan forms (k_shelf_scan, k_hrtf_uni<FLT>) cost in parity, stated as a test.  Their processor history
     differs from the engine's serial loop in the last bits (~1e-6 relative: other association, powers of M); a filter
