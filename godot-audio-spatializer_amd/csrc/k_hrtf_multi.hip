@@ -128,7 +128,9 @@ __global__ __launch_bounds__(MW * 64, GAS_HRTF_WAVES_PER_SIMD) void k_hrtf_multi
 		t2[k] = tw_lds[(8 + k) * 64 + lane];
 	}
 	const float lane_f = (float)lane;
-	uint32_t pf_word = 0; // GAS_MULTI_L2_PREFETCH: the word of the line touch in flight
+#if GAS_MULTI_L2_PREFETCH
+	uint32_t pf_word = 0; // the word of the line touch in flight
+#endif
 
 	for (uint32_t b = 0; b < K; b++) {
 		float *peaks_b = mb.peaks[b];
